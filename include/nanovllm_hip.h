@@ -1,0 +1,168 @@
+/*
+ * nanovllm_hip.h - C ABI of libnanovllm_hip.so: gfx950 (MI355X / CDNA4) kernels for
+ * the nano-vllm operator path.
+ *
+ * The reference has no FFI layer; each entry point below replaces one delegation the
+ * reference makes to a third-party / generated GPU kernel.  The citation on every
+ * declaration is the reference call site it stands in for (paths are relative to the
+ * reference repository).
+ *
+ * Conventions (all entry points)
+ *   - return 0 on success, a negative NVH_E* code on failure; nothing throws across the
+ *     ABI; nvh_last_error() returns a thread-local message for the last failure;
+ *   - every pointer is a DEVICE pointer owned by the caller (tensor.data_ptr()); the
+ *     library allocates nothing, never synchronises the host and launches only on the
+ *     `stream` argument (a hipStream_t passed as void*), so calls can be captured into a
+ *     hipGraph; scratch memory is passed in by the caller, sized by *_workspace_bytes();
+ *   - activations / weights / KV cache are bf16 (uint16 bit patterns); sizes are int64
+ *     element counts; strides are in ELEMENTS, given wherever the reference relies on a
+ *     strided view (q/k/v are slices of the fused qkv buffer: layers/attention.py:121-123);
+ *   - head_dim is 128 (every Qwen3 size); the KV page is 256 tokens (engine/sequence.py:73).
+ *   - single caller thread per device; asynchronous with respect to `stream`.
+ */
+#ifndef NANOVLLM_HIP_H
+#define NANOVLLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVH_OK 0
+#define NVH_EINVAL (-22)   /* bad shape / alignment / null pointer */
+#define NVH_ENOSYS (-38)   /* unsupported configuration (dtype, head_dim, group size) */
+#define NVH_ELAUNCH (-5)   /* hipLaunch / runtime error */
+#define NVH_ENODEV (-19)   /* device is not gfx950 */
+
+#define NVH_KV_PAGE 256
+#define NVH_HEAD_DIM 128
+
+typedef void* nvh_stream_t;
+
+/* ---- library ---- */
+int32_t nvh_version(void);
+const char* nvh_last_error(void);
+/* Refuses any device that is not gfx950.  Replaces the implicit CUDA device checks of
+ * engine/model_runner.py:121-127. */
+int32_t nvh_device_check(int32_t device_index);
+
+/* ---- K1: KV-cache scatter store.  layers/attention.py:34-127 (Triton store_kvcache_kernel).
+ * For token t: slot = slot_mapping[t]; slot < 0 -> skipped; otherwise cache row `slot`
+ * (row_elems = Hkv*D contiguous elements) <- key[t] / value[t].  num_slots bounds-checks
+ * nothing on the device; the caller guarantees slot < num_slots. */
+int32_t nvh_store_kvcache(const void* key, int64_t key_token_stride,
+                          const void* value, int64_t value_token_stride,
+                          void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                          int64_t num_tokens, int64_t row_elems, nvh_stream_t stream);
+
+/* ---- K4: RMSNorm.  layers/layernorm.py:57-93 (Inductor kernel of rms_forward).
+ * y = bf16(f32(x) * rsqrt(mean(x^2) + eps)) * w, rows of `dim` contiguous elements at the
+ * given row strides (x and y may alias). */
+int32_t nvh_rmsnorm(const void* x, int64_t x_row_stride, const void* weight,
+                    void* y, int64_t y_row_stride, int64_t rows, int64_t dim, float eps,
+                    nvh_stream_t stream);
+
+/* ---- K5: fused residual add + RMSNorm.  layers/layernorm.py:95-141 (add_rms_forward).
+ * s = f32(x)+f32(residual); residual <- bf16(s) (in place); y = bf16(s*rsqrt(mean(s^2)+eps))*w.
+ * When `partials` is non-null, x is ignored and bf16(sum_i partials[i]) is used in its
+ * place: `num_partials` fp32 slabs of [rows, dim] written by a split-K nvh_gemm_bf16_nt. */
+int32_t nvh_add_rmsnorm(const void* x, void* residual, const void* weight, void* y,
+                        int64_t rows, int64_t dim, float eps,
+                        const float* partials, int64_t num_partials, nvh_stream_t stream);
+
+/* ---- K6: rotary embedding, half-split rotation in fp32.
+ * layers/rotary_embedding.py:27-65,114-153 (Inductor kernel of RotaryEmbedding.forward).
+ * cos_sin: fp32 [max_position, D] (cos | sin halves); positions int64 [T]; q [T,Hq,D] and
+ * k [T,Hkv,D] rotated in place, token strides in elements. */
+int32_t nvh_rope(const int64_t* positions, void* q, int64_t q_token_stride, int64_t num_q_heads,
+                 void* k, int64_t k_token_stride, int64_t num_kv_heads,
+                 const float* cos_sin, int64_t max_position, int64_t num_tokens, int64_t head_dim,
+                 nvh_stream_t stream);
+
+/* Fused per-head RMSNorm(q), RMSNorm(k) -> RoPE -> KV-cache store over the fused qkv
+ * buffer [T, (Hq+2Hkv)*D]: q and k are updated in place, k and v rows are copied to their
+ * cache slots (slot < 0 or null caches: no store).  Same arithmetic and rounding points as
+ * nvh_rmsnorm + nvh_rope + nvh_store_kvcache in sequence, i.e. models/qwen3.py:191-197. */
+int32_t nvh_qknorm_rope_store(void* qkv, int64_t token_stride, int64_t num_q_heads, int64_t num_kv_heads,
+                              const void* q_norm_weight, const void* k_norm_weight, float eps,
+                              const int64_t* positions, const float* cos_sin, int64_t max_position,
+                              void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                              int64_t num_tokens, nvh_stream_t stream);
+
+/* ---- K7: SiLU(x[:, :I]) * x[:, I:].  layers/activation.py:36-58.  x [rows, 2I] -> y [rows, I]. */
+int32_t nvh_silu_mul(const void* x, void* y, int64_t rows, int64_t inter, nvh_stream_t stream);
+
+/* ---- E1: embedding row gather with vocab-parallel masking.  layers/embed_head.py:95-131.
+ * ids int64 [T]; table [vocab_rows, dim]; ids outside [vocab_start, vocab_start+vocab_rows)
+ * produce zero rows. */
+int32_t nvh_embedding(const int64_t* ids, const void* table, void* out, int64_t num_tokens,
+                      int64_t dim, int64_t vocab_start, int64_t vocab_rows, nvh_stream_t stream);
+
+/* Row selection for the LM head.  layers/embed_head.py:197-202: row i of `out` is
+ * hidden[cu_seqlens_q[j+1]-1] with j = need[i] (need non-null) or j = i. */
+int32_t nvh_gather_last_rows(const void* hidden, const int32_t* cu_seqlens_q, const int32_t* need,
+                             void* out, int64_t num_rows, int64_t dim, nvh_stream_t stream);
+
+/* ---- G1-G5: y[M,N] = x[M,K] @ W[N,K]^T (+ bias[N]), fp32 accumulation, bf16 out.
+ * layers/linear.py:130,198,407 and layers/embed_head.py:204 (F.linear -> cuBLAS).
+ * K % 64 == 0.  split_k > 1: fp32 partial slabs [split_k, M, N] are written to `workspace`
+ * instead of y (consumed by nvh_add_rmsnorm or nvh_splitk_reduce); bias must be null then. */
+int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const void* w, const void* bias,
+                         void* y, int64_t y_row_stride, int64_t M, int64_t N, int64_t K,
+                         int32_t split_k, float* workspace, nvh_stream_t stream);
+int64_t nvh_gemm_workspace_bytes(int64_t M, int64_t N, int32_t split_k);
+/* Suggested split (1 = none) for a weight-streaming GEMM of this shape on 256 CUs. */
+int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K);
+/* y = bf16(sum of slabs (+bias)). */
+int32_t nvh_splitk_reduce(const float* partials, int64_t num_partials, const void* bias,
+                          void* y, int64_t y_row_stride, int64_t M, int64_t N, nvh_stream_t stream);
+
+/* ---- K2: paged / packed var-len causal GQA attention (prefill, chunked prefill, mixed).
+ * layers/attention.py:236-248 (flash_attn_varlen_func).  q [T,Hq,D] packed by
+ * cu_seqlens_q[B+1].  block_tables == NULL: k,v are the packed new tokens [Tk,Hkv,D]
+ * indexed by cu_seqlens_k (token strides given); otherwise k,v are the page pools
+ * [num_pages,256,Hkv,D] and block_tables is int32 [B, table_stride] (entries past
+ * ceil(len/256) are never read).  Mask: query i of a sequence with Lq queries / Lk keys
+ * sees keys j <= i + (Lk - Lq).  softmax in fp32, out bf16 [T,Hq,D] contiguous. */
+int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride,
+                        const void* k, const void* v, int64_t kv_token_stride,
+                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                        const int32_t* block_tables, int64_t table_stride,
+                        int64_t batch, int64_t max_seqlen_q, int64_t total_q,
+                        int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                        float softmax_scale, void* out, nvh_stream_t stream);
+
+/* ---- K3: paged decode attention, one query per sequence.
+ * layers/attention.py:222-234 (flash_attn_with_kvcache).  q [B,Hq,D]; context_lens int32 [B]
+ * (0 = padded row -> zero output); new K/V already stored.  num_splits > 1 splits every
+ * sequence's keys over that many workgroups (fixed grid: safe under graph replay with
+ * changing context_lens) and needs `workspace`. */
+int32_t nvh_attn_decode(const void* q, int64_t q_token_stride,
+                        const void* k_cache, const void* v_cache,
+                        const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                        int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                        float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                        nvh_stream_t stream);
+int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t head_dim, int32_t num_splits);
+int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int64_t max_context);
+
+/* ---- K8: sampling.  layers/sampler.py:41-81.
+ * nvh_sample: p = softmax(f32(logits)/T); token = argmax(p / max(E,1e-10)), E ~ Exp(1) from
+ * a counter-based generator keyed by (seed, offset, row, column).
+ * nvh_sample_with_noise: same with the noise tensor supplied (fp32 [rows, vocab]).
+ * nvh_argmax: lowest index of the row maximum (the pre-sampler greedy token).
+ * logits bf16 or fp32 (logits_is_f32), row stride in elements; out int64 [rows]. */
+int32_t nvh_sample(const void* logits, int32_t logits_is_f32, int64_t row_stride, const float* temperatures,
+                   int64_t* out, int64_t rows, int64_t vocab, uint64_t seed, uint64_t offset,
+                   nvh_stream_t stream);
+int32_t nvh_sample_with_noise(const void* logits, int32_t logits_is_f32, int64_t row_stride,
+                              const float* temperatures, const float* noise, int64_t* out,
+                              int64_t rows, int64_t vocab, nvh_stream_t stream);
+int32_t nvh_argmax(const void* logits, int32_t logits_is_f32, int64_t row_stride, int64_t* out,
+                   int64_t rows, int64_t vocab, nvh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOVLLM_HIP_H */

@@ -1,0 +1,233 @@
+// Paged decode attention (one query per sequence): HBM-bound streaming of the KV pages.
+//
+// Grid (num_splits, Hkv, B); 256 threads.  A workgroup owns one (sequence, kv head, key
+// range) and serves all G = Hq/Hkv query heads of that kv head, so every K/V byte is read
+// from HBM once.  Lane layout: 16 consecutive lanes ("row") cover one token's 256-byte K
+// (or V) row of this head with one 16-byte load each; a wave holds 4 rows, the workgroup 16,
+// and each loop trip consumes 64 consecutive tokens (always inside one 256-token page, so the
+// block-table entry is a single scalar load per trip).  Every row keeps its own online-softmax
+// state (max, sum, 8 output columns per lane); rows are merged once at the end (shuffles inside
+// the wave, LDS across waves).  With num_splits > 1 the per-range results go to a workspace as
+// (max, sum, unnormalised fp32 output) and attn_decode_combine_kernel finishes them.
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+
+template <int G>
+__global__ __launch_bounds__(256) void attn_decode_kernel(
+    const bf16* __restrict__ q, int64_t q_stride, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+    const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ tables, int64_t table_stride, int hkv,
+    float scale_log2, bf16* __restrict__ out, float* __restrict__ ws_acc, float* __restrict__ ws_ml) {
+    __shared__ float sm_acc[4][G][128];
+    __shared__ float sm_ml[4][G][2];
+
+    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int num_splits = gridDim.x;
+    const int hq = hkv * G;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15;
+    const int rowid = w * 4 + (lane >> 4);
+
+    const int ctx = ctx_lens[b];
+    const int chunk = (((ctx + num_splits - 1) / num_splits) + 63) & ~63;
+    const int start = split * chunk;
+    const int end = min(ctx, start + chunk);
+
+    bf16x8 qv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        qv[g] = *reinterpret_cast<const bf16x8*>(q + (int64_t)b * q_stride + (int64_t)(kvh * G + g) * 128 + c * 8);
+
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+
+    const int32_t* table = tables + (int64_t)b * table_stride;
+    for (int base = start; base < end; base += 64) {
+        const int64_t slot0 = (int64_t)table[base >> 8] * NVH_KV_PAGE + (base & 255);
+        bf16x8 kf[4], vf[4];
+        bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int toff = u * 16 + rowid;
+            valid[u] = base + toff < end;
+            const int64_t off = ((slot0 + (valid[u] ? toff : 0)) * hkv + kvh) * 128 + c * 8;
+            kf[u] = *reinterpret_cast<const bf16x8*>(kc + off);
+            vf[u] = *reinterpret_cast<const bf16x8*>(vc + off);
+        }
+        float s[G][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf16x2 a = {qv[g][2 * j], qv[g][2 * j + 1]};
+                    bf16x2 k2 = {kf[u][2 * j], kf[u][2 * j + 1]};
+                    d = __builtin_amdgcn_fdot2_f32_bf16(a, k2, d, false);
+                }
+                d = row16_sum(d) * scale_log2;
+                s[g][u] = valid[u] ? d : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float mn = fmaxf(fmaxf(fmaxf(s[g][0], s[g][1]), fmaxf(s[g][2], s[g][3])), m[g]);
+            const float mu = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = __builtin_amdgcn_exp2f(m[g] - mu);
+            float p[4];
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p[u] = __builtin_amdgcn_exp2f(s[g][u] - mu);
+                ps += p[u];
+            }
+            l[g] = l[g] * alpha + ps;
+            m[g] = mn;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float a = acc[g][j] * alpha;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += p[u] * bf2f(vf[u][j]);
+                acc[g][j] = a;
+            }
+        }
+    }
+
+    // merge the 4 rows of the wave (lanes l, l^16, l^32 hold the same output columns)
+#pragma unroll
+    for (int step = 16; step <= 32; step <<= 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float mo = __shfl_xor(m[g], step, 64);
+            const float lo = __shfl_xor(l[g], step, 64);
+            const float mn = fmaxf(m[g], mo);
+            const float mu = (mn == -INFINITY) ? 0.f : mn;
+            const float a = __builtin_amdgcn_exp2f(m[g] - mu), bsc = __builtin_amdgcn_exp2f(mo - mu);
+            l[g] = l[g] * a + lo * bsc;
+            m[g] = mn;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float ao = __shfl_xor(acc[g][j], step, 64);
+                acc[g][j] = acc[g][j] * a + ao * bsc;
+            }
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm_acc[w][g][c * 8 + j] = acc[g][j];
+            if (c == 0) {
+                sm_ml[w][g][0] = m[g];
+                sm_ml[w][g][1] = l[g];
+            }
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < G * 128; idx += 256) {
+        const int g = idx >> 7, d = idx & 127;
+        float M = fmaxf(fmaxf(sm_ml[0][g][0], sm_ml[1][g][0]), fmaxf(sm_ml[2][g][0], sm_ml[3][g][0]));
+        const float mu = (M == -INFINITY) ? 0.f : M;
+        float L = 0.f, A = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const float sc = __builtin_amdgcn_exp2f(sm_ml[ww][g][0] - mu);
+            L += sm_ml[ww][g][1] * sc;
+            A += sm_acc[ww][g][d] * sc;
+        }
+        const int h = kvh * G + g;
+        if (num_splits == 1) {
+            out[((int64_t)b * hq + h) * 128 + d] = f2bf(L > 0.f ? A / L : 0.f);
+        } else {
+            const int64_t slab = ((int64_t)b * hq + h) * num_splits + split;
+            ws_acc[slab * 128 + d] = A;
+            if (d == 0) {
+                ws_ml[slab * 2] = M;
+                ws_ml[slab * 2 + 1] = L;
+            }
+        }
+    }
+}
+
+// One workgroup of 128 threads per (sequence, query head): merge the per-range partials.
+__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
+                                                                  const float* __restrict__ ws_ml,
+                                                                  bf16* __restrict__ out, int num_splits) {
+    const int64_t bh = blockIdx.x;
+    const int d = threadIdx.x;
+    float M = -INFINITY;
+    for (int s = 0; s < num_splits; ++s) M = fmaxf(M, ws_ml[(bh * num_splits + s) * 2]);
+    const float mu = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f, A = 0.f;
+    for (int s = 0; s < num_splits; ++s) {
+        const int64_t slab = bh * num_splits + s;
+        const float sc = __builtin_amdgcn_exp2f(ws_ml[slab * 2] - mu);
+        L += ws_ml[slab * 2 + 1] * sc;
+        A += ws_acc[slab * 128 + d] * sc;
+    }
+    out[bh * 128 + d] = f2bf(L > 0.f ? A / L : 0.f);
+}
+
+extern "C" int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t head_dim, int32_t num_splits) {
+    if (num_splits <= 1) return 0;
+    return batch * num_q_heads * num_splits * (head_dim + 2) * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int64_t max_context) {
+    // Aim for >= 1024 workgroups (4 per CU) while keeping >= 128 keys per range.
+    const int64_t wgs = batch * num_kv_heads;
+    int64_t want = nvh_cdiv(1024, wgs > 0 ? wgs : 1);
+    const int64_t cap = max_context / 128 > 1 ? max_context / 128 : 1;
+    if (want > cap) want = cap;
+    if (want > 64) want = 64;
+    return (int32_t)(want < 1 ? 1 : want);
+}
+
+extern "C" int32_t nvh_attn_decode(const void* q, int64_t q_token_stride, const void* k_cache, const void* v_cache,
+                                   const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                   int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                   float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                                   nvh_stream_t stream) {
+    NVH_REQUIRE(q && k_cache && v_cache && context_lens && block_tables && out, NVH_EINVAL, "nvh_attn_decode: null pointer");
+    NVH_REQUIRE(head_dim == 128, NVH_ENOSYS, "nvh_attn_decode: head_dim %ld unsupported (128 only)", (long)head_dim);
+    NVH_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, NVH_EINVAL, "nvh_attn_decode: Hq %% Hkv != 0");
+    NVH_REQUIRE(q_token_stride % 8 == 0 && nvh_aligned16(q) && nvh_aligned16(k_cache) && nvh_aligned16(v_cache), NVH_EINVAL,
+                "nvh_attn_decode: 16-byte alignment required");
+    NVH_REQUIRE(num_splits >= 1 && num_splits <= 256 && (num_splits == 1 || workspace), NVH_EINVAL,
+                "nvh_attn_decode: num_splits %d needs a workspace", num_splits);
+    NVH_REQUIRE(batch <= 65535 && num_kv_heads <= 65535, NVH_EINVAL, "nvh_attn_decode: batch/heads exceed grid limits");
+    if (batch == 0) return NVH_OK;
+    const int g = (int)(num_q_heads / num_kv_heads);
+    float* ws_acc = (float*)workspace;
+    float* ws_ml = ws_acc ? ws_acc + batch * num_q_heads * num_splits * 128 : nullptr;
+    dim3 grid((unsigned)num_splits, (unsigned)num_kv_heads, (unsigned)batch);
+    const float sl2 = softmax_scale * LOG2E;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_DEC(GG)                                                                                              \
+    attn_decode_kernel<GG><<<grid, 256, 0, st>>>((const bf16*)q, q_token_stride, (const bf16*)k_cache,             \
+                                                 (const bf16*)v_cache, context_lens, block_tables, table_stride,   \
+                                                 (int)num_kv_heads, sl2, (bf16*)out, ws_acc, ws_ml)
+    switch (g) {
+        case 1: LAUNCH_DEC(1); break;
+        case 2: LAUNCH_DEC(2); break;
+        case 4: LAUNCH_DEC(4); break;
+        case 5: LAUNCH_DEC(5); break;
+        case 8: LAUNCH_DEC(8); break;
+        default:
+            nvh_set_error("nvh_attn_decode: group size Hq/Hkv = %d unsupported (1,2,4,5,8)", g);
+            return NVH_ENOSYS;
+    }
+#undef LAUNCH_DEC
+    NVH_CHECK_LAUNCH("attn_decode");
+    if (num_splits > 1) {
+        attn_decode_combine_kernel<<<(unsigned)(batch * num_q_heads), 128, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits);
+        NVH_CHECK_LAUNCH("attn_decode_combine");
+    }
+    return NVH_OK;
+}

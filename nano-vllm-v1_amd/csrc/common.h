@@ -1,0 +1,79 @@
+// Shared device helpers and host-side error plumbing for libnanovllm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/nanovllm_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// ---- host side --------------------------------------------------------------------
+void nvh_set_error(const char* fmt, ...);
+
+#define NVH_REQUIRE(cond, code, ...)          \
+    do {                                      \
+        if (!(cond)) {                        \
+            nvh_set_error(__VA_ARGS__);       \
+            return (code);                    \
+        }                                     \
+    } while (0)
+
+#define NVH_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            nvh_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return NVH_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline bool nvh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int64_t nvh_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device side ------------------------------------------------------------------
+// Sum / max over the 16 lanes of a DPP row (lanes 16r..16r+15); every lane of the row
+// receives the result.  quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror, row_mirror.
+#define NVH_DPP(x, ctrl) \
+    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xF, 0xF, true))
+
+__device__ __forceinline__ float row16_sum(float x) {
+    x += NVH_DPP(x, 0xB1);
+    x += NVH_DPP(x, 0x4E);
+    x += NVH_DPP(x, 0x141);
+    x += NVH_DPP(x, 0x140);
+    return x;
+}
+__device__ __forceinline__ float row16_max(float x) {
+    x = fmaxf(x, NVH_DPP(x, 0xB1));
+    x = fmaxf(x, NVH_DPP(x, 0x4E));
+    x = fmaxf(x, NVH_DPP(x, 0x141));
+    x = fmaxf(x, NVH_DPP(x, 0x140));
+    return x;
+}
+// Full 64-lane reductions (result in every lane).
+__device__ __forceinline__ float wave_sum(float x) {
+    x = row16_sum(x);
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+    x = row16_max(x);
+    x = fmaxf(x, __shfl_xor(x, 16, 64));
+    x = fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
+}
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }

@@ -1,0 +1,230 @@
+// y[M,N] = x[M,K] @ W[N,K]^T (+bias): bf16 in, fp32 MFMA accumulation, bf16 out (or fp32
+// split-K slabs).  Both operands are K-contiguous, which is exactly the MFMA 16x16x32 bf16
+// fragment shape (8 consecutive k per lane), so tiles go global -> LDS by 16-byte LDS-DMA
+// (global_load_lds) with no register staging and no transposes.
+//
+// Workgroup = 4 waves, tile BM(x rows) x BN(W rows) x 64(k), double-buffered LDS, one
+// barrier per k-tile: the DMA of tile t+1 is in flight while tile t is multiplied.
+// W rows are the MFMA "A" operand and x rows the "B" operand, so each lane ends up with 4
+// consecutive output columns (n) of one output row (m) -> 8-byte bf16 / 16-byte fp32 stores.
+//
+// LDS tile rows are 128 B (64 k).  16-byte chunk `c` of tile row `r` is stored at chunk
+// position c ^ ((r >> 1) & 7): with that XOR every 16-lane group of a ds_read_b128 fragment
+// read touches all 64 banks exactly once.  LDS-DMA writes lane-linear, so the XOR is applied
+// to the per-lane SOURCE address and again on the read.
+//
+// Small M (decode) uses BM = 16/32/64 so the grid is set by N; split-K (gridDim.z) spreads
+// narrow-N projections over the chip, writing fp32 slabs that the consumer kernel sums.
+#include "common.h"
+
+#define BK 64
+
+template <int BM, int BN, int WAVES_N, int WAVES_M>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
+    const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
+    bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split) {
+    static_assert(WAVES_N * WAVES_M == 4, "4 waves");
+    constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
+    constexpr int TN = WN / 16, TM = WM / 16;             // 16x16 MFMA tiles per wave
+    constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128;
+    constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_GROUPS = BN / 8, B_GROUPS = BM / 8;   // 8-row x 128-B pieces = one DMA each
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int ntiles = (kend - kbeg) / BK;
+
+    // per-lane DMA source: row (lane>>3) of the 8-row piece, chunk position lane&7
+    const int dma_r = lane >> 3, dma_pos = lane & 7;
+
+    auto stage = [&](int t, int buf) {
+        const int k0 = kbeg + t * BK;
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < (A_GROUPS + 3) / 4; ++i) {
+            const int grp = wave + i * 4;
+            if (grp < A_GROUPS) {
+                const int r = grp * 8 + dma_r;
+                const int chunk = dma_pos ^ ((r >> 1) & 7);
+                const int gr = min(n0 + r, N - 1);
+                const bf16* src = w + (int64_t)gr * K + k0 + chunk * 8;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(base + grp * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (B_GROUPS + 3) / 4; ++i) {
+            const int grp = wave + i * 4;
+            if (grp < B_GROUPS) {
+                const int r = grp * 8 + dma_r;
+                const int chunk = dma_pos ^ ((r >> 1) & 7);
+                const int gr = min(m0 + r, M - 1);
+                const bf16* src = x + (int64_t)gr * x_stride + k0 + chunk * 8;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(base + A_BYTES + grp * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    if (ntiles > 0) stage(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+        const char* a_base = smem + (t & 1) * STAGE_BYTES;
+        const char* b_base = a_base + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TN], bfr[TM];
+            const int kc = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * WN + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(a_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * WM + j * 16 + fr;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds n = n_base + fq*4 .. +3 of row m = m_base + fr
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wn * WN + i * 16 + fq * 4;
+        if (n >= N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr) {
+            const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WM + j * 16 + fr;
+            if (m >= M) continue;
+            if (partials != nullptr) {
+                *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.z * M + m) * N + n) = acc[i][j];
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e] + bv[e]);
+                *reinterpret_cast<bf16x4*>(y + (int64_t)m * y_stride + n) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_N, int WAVES_M>
+static void launch_gemm(const bf16* x, int64_t xs, const bf16* w, const bf16* bias, bf16* y, int64_t ys, float* partials,
+                        int M, int N, int K, int split_k, hipStream_t st) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool configured = false;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M>;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+    }
+    const int ktiles = K / BK;
+    const int k_per_split = (int)nvh_cdiv(ktiles, split_k) * BK;
+    dim3 grid((unsigned)nvh_cdiv(N, BN), (unsigned)nvh_cdiv(M, BM), (unsigned)split_k);
+    kern<<<grid, 256, smem, st>>>(x, xs, w, bias, y, ys, partials, M, N, K, k_per_split);
+}
+
+extern "C" int64_t nvh_gemm_workspace_bytes(int64_t M, int64_t N, int32_t split_k) {
+    return split_k > 1 ? (int64_t)split_k * M * N * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K) {
+    // Enough workgroups to cover 256 CUs, at least 4 k-tiles (256 k) per split, at most 16 slabs.
+    const int64_t bm = M <= 16 ? 16 : M <= 32 ? 32 : M <= 64 ? 64 : 128;
+    const int64_t tiles = nvh_cdiv(N, 128) * nvh_cdiv(M, bm);
+    if (tiles >= 192) return 1;
+    int64_t s = nvh_cdiv(256, tiles);
+    const int64_t kmax = K / 256 > 1 ? K / 256 : 1;
+    if (s > kmax) s = kmax;
+    if (s > 16) s = 16;
+    return (int32_t)(s < 1 ? 1 : s);
+}
+
+extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const void* w, const void* bias, void* y,
+                                    int64_t y_row_stride, int64_t M, int64_t N, int64_t K, int32_t split_k,
+                                    float* workspace, nvh_stream_t stream) {
+    NVH_REQUIRE(x && w && (y || workspace), NVH_EINVAL, "nvh_gemm_bf16_nt: null pointer");
+    NVH_REQUIRE(K > 0 && K % BK == 0, NVH_EINVAL, "nvh_gemm_bf16_nt: K=%ld must be a multiple of 64", (long)K);
+    NVH_REQUIRE(N > 0 && N % 4 == 0, NVH_EINVAL, "nvh_gemm_bf16_nt: N=%ld must be a multiple of 4", (long)N);
+    NVH_REQUIRE(M >= 0 && M < (1 << 30) && N < (1 << 30), NVH_EINVAL, "nvh_gemm_bf16_nt: M/N out of range");
+    NVH_REQUIRE(x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w), NVH_EINVAL, "nvh_gemm_bf16_nt: x/w rows must be 16-byte aligned");
+    NVH_REQUIRE(split_k >= 1 && split_k <= 64, NVH_EINVAL, "nvh_gemm_bf16_nt: split_k %d out of range", split_k);
+    if (split_k > 1) {
+        NVH_REQUIRE(workspace && nvh_aligned16(workspace), NVH_EINVAL, "nvh_gemm_bf16_nt: split_k needs a 16-byte aligned workspace");
+        NVH_REQUIRE(!bias, NVH_EINVAL, "nvh_gemm_bf16_nt: bias is applied by the split-K consumer");
+        NVH_REQUIRE(K / BK >= split_k, NVH_EINVAL, "nvh_gemm_bf16_nt: split_k %d exceeds the %ld k-tiles", split_k, (long)(K / BK));
+    } else {
+        NVH_REQUIRE(y && y_row_stride % 4 == 0 && ((uintptr_t)y & 7) == 0, NVH_EINVAL, "nvh_gemm_bf16_nt: y rows must be 8-byte aligned");
+        NVH_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0, NVH_EINVAL, "nvh_gemm_bf16_nt: bias must be 8-byte aligned");
+    }
+    if (M == 0) return NVH_OK;
+    float* partials = split_k > 1 ? workspace : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const bf16 *xp = (const bf16*)x, *wp = (const bf16*)w, *bp = (const bf16*)bias;
+    bf16* yp = (bf16*)y;
+    if (M <= 16)
+        launch_gemm<16, 128, 4, 1>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
+    else if (M <= 32)
+        launch_gemm<32, 128, 4, 1>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
+    else if (M <= 64)
+        launch_gemm<64, 128, 2, 2>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
+    else
+        launch_gemm<128, 128, 2, 2>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
+    NVH_CHECK_LAUNCH("gemm_bf16_nt");
+    return NVH_OK;
+}
+
+// ------------------------------------------------------------------ split-K slab reduction
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partials, int num_partials,
+                                                            const bf16* __restrict__ bias, bf16* __restrict__ y,
+                                                            int64_t y_stride, int64_t M, int N) {
+    const int cpr = N >> 2;
+    const int64_t total = M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / cpr;
+        const int n = (int)(i % cpr) * 4;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < num_partials; ++p) a += *reinterpret_cast<const f32x4*>(partials + ((int64_t)p * M + m) * N + n);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(a[e] + (bias ? bf2f(bias[n + e]) : 0.f));
+        *reinterpret_cast<bf16x4*>(y + m * y_stride + n) = o;
+    }
+}
+
+extern "C" int32_t nvh_splitk_reduce(const float* partials, int64_t num_partials, const void* bias, void* y,
+                                     int64_t y_row_stride, int64_t M, int64_t N, nvh_stream_t stream) {
+    NVH_REQUIRE(partials && y, NVH_EINVAL, "nvh_splitk_reduce: null pointer");
+    NVH_REQUIRE(N % 4 == 0 && y_row_stride % 4 == 0 && nvh_aligned16(partials) && ((uintptr_t)y & 7) == 0, NVH_EINVAL,
+                "nvh_splitk_reduce: alignment");
+    if (M == 0) return NVH_OK;
+    const int64_t total = M * (N / 4);
+    const unsigned grid = (unsigned)(nvh_cdiv(total, 256) < 2048 ? nvh_cdiv(total, 256) : 2048);
+    splitk_reduce_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(partials, (int)num_partials, (const bf16*)bias, (bf16*)y,
+                                                                y_row_stride, M, (int)N);
+    NVH_CHECK_LAUNCH("splitk_reduce");
+    return NVH_OK;
+}

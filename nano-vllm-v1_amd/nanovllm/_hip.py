@@ -1,0 +1,71 @@
+"""ctypes binding of libnanovllm_hip.so (the C ABI declared in include/nanovllm_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails, an
+exception is raised.  Build the library with ``nano-vllm-v1_amd/csrc/build.sh``
+(or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(os.environ.get("NANOVLLM_HIP_LIB", Path(__file__).resolve().parent.parent / "lib" / "libnanovllm_hip.so"))
+
+i32, i64, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/nanovllm_hip.h one to one.
+SIGNATURES = {
+    "nvh_version": (i32, []),
+    "nvh_last_error": (C.c_char_p, []),
+    "nvh_device_check": (i32, [i32]),
+    "nvh_store_kvcache": (i32, [vp, i64, vp, i64, vp, vp, vp, i64, i64, vp]),
+    "nvh_rmsnorm": (i32, [vp, i64, vp, vp, i64, i64, i64, f32, vp]),
+    "nvh_add_rmsnorm": (i32, [vp, vp, vp, vp, i64, i64, f32, vp, i64, vp]),
+    "nvh_rope": (i32, [vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, vp]),
+    "nvh_qknorm_rope_store": (i32, [vp, i64, i64, i64, vp, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp]),
+    "nvh_silu_mul": (i32, [vp, vp, i64, i64, vp]),
+    "nvh_embedding": (i32, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "nvh_gather_last_rows": (i32, [vp, vp, vp, vp, i64, i64, vp]),
+    "nvh_gemm_bf16_nt": (i32, [vp, i64, vp, vp, vp, i64, i64, i64, i64, i32, vp, vp]),
+    "nvh_gemm_workspace_bytes": (i64, [i64, i64, i32]),
+    "nvh_gemm_suggest_split_k": (i32, [i64, i64, i64]),
+    "nvh_splitk_reduce": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
+    "nvh_attn_varlen": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, f32, vp, vp]),
+    "nvh_attn_decode": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
+    "nvh_attn_decode_workspace_bytes": (i64, [i64, i64, i64, i32]),
+    "nvh_attn_decode_suggest_splits": (i32, [i64, i64, i64]),
+    "nvh_sample": (i32, [vp, i32, i64, vp, vp, i64, i64, u64, u64, vp]),
+    "nvh_sample_with_noise": (i32, [vp, i32, i64, vp, vp, vp, i64, i64, vp]),
+    "nvh_argmax": (i32, [vp, i32, i64, vp, i64, i64, vp]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            raise HipError(f"{_LIB_PATH} not found: build it with nano-vllm-v1_amd/csrc/build.sh; "
+                           "there is no CPU or PyTorch fallback for the operator path")
+        handle = C.CDLL(str(_LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise HipError(f"{what} failed ({code}): {lib().nvh_last_error().decode()}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(lib(), name)(*args), name)

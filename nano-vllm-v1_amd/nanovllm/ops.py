@@ -1,0 +1,258 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point).
+
+Each wrapper checks what the kernels assume (device, dtype, contiguity of the
+innermost dimension), allocates outputs / workspaces through torch's caching
+allocator (so calls are graph-capturable), and launches on torch's current
+stream.  bf16 only: the operator path has no other precision.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+
+BF16 = torch.bfloat16
+KV_PAGE = 256
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _gpu_bf16(*tensors):
+    for t in tensors:
+        if not (t.is_cuda and t.dtype == BF16):
+            raise TypeError(f"expected a bf16 GPU tensor, got {t.dtype} on {t.device}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+# ---------------------------------------------------------------- norms
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    """x [..., dim] -> normalised copy (a strided view, e.g. q inside the fused qkv buffer, is
+    compacted first; the model's own forward uses the fused qknorm_rope_store_ instead)."""
+    _gpu_bf16(x, weight)
+    dim = x.shape[-1]
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    rows = x.numel() // dim
+    _hip.call("nvh_rmsnorm", x.data_ptr(), dim, weight.data_ptr(), out.data_ptr(), dim, rows, dim, float(eps), _stream())
+    return out
+
+
+def add_rmsnorm(x: torch.Tensor | None, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                partials: torch.Tensor | None = None) -> tuple[torch.Tensor, torch.Tensor]:
+    """(y, residual): residual is updated IN PLACE to bf16(x + residual).  With ``partials``
+    (fp32 [S, rows, dim] split-K slabs) x is bf16(sum of slabs)."""
+    _gpu_bf16(residual, weight)
+    dim = residual.shape[-1]
+    rows = residual.numel() // dim
+    assert residual.is_contiguous()
+    y = torch.empty_like(residual)
+    if partials is not None:
+        assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape[-2:] == (rows, dim)
+        _hip.call("nvh_add_rmsnorm", 0, residual.data_ptr(), weight.data_ptr(), y.data_ptr(), rows, dim, float(eps),
+                  partials.data_ptr(), partials.shape[0], _stream())
+    else:
+        _gpu_bf16(x)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        _hip.call("nvh_add_rmsnorm", x.data_ptr(), residual.data_ptr(), weight.data_ptr(), y.data_ptr(), rows, dim,
+                  float(eps), 0, 0, _stream())
+    return y, residual
+
+
+# ---------------------------------------------------------------- rotary / fused qkv epilogue
+def rope_(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, cos_sin: torch.Tensor) -> None:
+    """In-place rotation of q [T,Hq,D] and k [T,Hkv,D] (views with head stride D allowed)."""
+    _gpu_bf16(q, k)
+    assert positions.dtype == torch.int64 and cos_sin.dtype == torch.float32 and cos_sin.is_contiguous()
+    t, hq, d = q.shape
+    hkv = k.shape[1]
+    assert q.stride(2) == 1 and q.stride(1) == d and k.stride(2) == 1 and k.stride(1) == d
+    _hip.call("nvh_rope", positions.data_ptr(), q.data_ptr(), q.stride(0), hq, k.data_ptr(), k.stride(0), hkv,
+              cos_sin.data_ptr(), cos_sin.shape[0], t, d, _stream())
+
+
+def qknorm_rope_store_(qkv: torch.Tensor, num_q_heads: int, num_kv_heads: int, q_weight, k_weight, eps: float,
+                       positions, cos_sin, k_cache, v_cache, slot_mapping) -> None:
+    """Fused per-head RMSNorm + RoPE on the q/k parts of qkv [T, (Hq+2Hkv)*128] in place,
+    and K/V scatter into the caches (skipped when the caches are None)."""
+    _gpu_bf16(qkv, q_weight, k_weight)
+    assert qkv.stride(1) == 1 and positions.dtype == torch.int64
+    store = k_cache is not None and k_cache.numel() > 0 and slot_mapping is not None and slot_mapping.numel() > 0
+    _hip.call("nvh_qknorm_rope_store", qkv.data_ptr(), qkv.stride(0), num_q_heads, num_kv_heads, q_weight.data_ptr(),
+              k_weight.data_ptr(), float(eps), positions.data_ptr(), cos_sin.data_ptr(), cos_sin.shape[0],
+              k_cache.data_ptr() if store else 0, v_cache.data_ptr() if store else 0,
+              slot_mapping.data_ptr() if store else 0, qkv.shape[0], _stream())
+
+
+def store_kvcache(key, value, k_cache, v_cache, slot_mapping) -> None:
+    _gpu_bf16(key, value, k_cache, v_cache)
+    n, h, d = key.shape
+    assert key.stride(-1) == 1 and value.stride(-1) == 1 and key.stride(1) == d and value.stride(1) == d
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and slot_mapping.dtype == torch.int32
+    assert slot_mapping.numel() == n
+    _hip.call("nvh_store_kvcache", key.data_ptr(), key.stride(0), value.data_ptr(), value.stride(0), k_cache.data_ptr(),
+              v_cache.data_ptr(), slot_mapping.data_ptr(), n, h * d, _stream())
+
+
+# ---------------------------------------------------------------- activation / gathers
+def silu_mul(x: torch.Tensor) -> torch.Tensor:
+    _gpu_bf16(x)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    inter = x.shape[-1] // 2
+    rows = x.numel() // (2 * inter)
+    y = torch.empty(*x.shape[:-1], inter, dtype=BF16, device=x.device)
+    _hip.call("nvh_silu_mul", x.data_ptr(), y.data_ptr(), rows, inter, _stream())
+    return y
+
+
+def embedding(ids: torch.Tensor, table: torch.Tensor, vocab_start: int = 0) -> torch.Tensor:
+    _gpu_bf16(table)
+    assert ids.dtype == torch.int64 and ids.is_cuda and table.is_contiguous()
+    out = torch.empty(ids.numel(), table.shape[1], dtype=BF16, device=table.device)
+    _hip.call("nvh_embedding", ids.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), table.shape[1],
+              vocab_start, table.shape[0], _stream())
+    return out
+
+
+def gather_last_rows(hidden: torch.Tensor, cu_seqlens_q: torch.Tensor, need: torch.Tensor | None, num_rows: int) -> torch.Tensor:
+    _gpu_bf16(hidden)
+    assert hidden.is_contiguous() and cu_seqlens_q.dtype == torch.int32
+    out = torch.empty(num_rows, hidden.shape[1], dtype=BF16, device=hidden.device)
+    _hip.call("nvh_gather_last_rows", hidden.data_ptr(), cu_seqlens_q.data_ptr(), _p(need), out.data_ptr(), num_rows,
+              hidden.shape[1], _stream())
+    return out
+
+
+# ---------------------------------------------------------------- GEMM
+def suggest_split_k(m: int, n: int, k: int) -> int:
+    return _hip.lib().nvh_gemm_suggest_split_k(m, n, k)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """y = x @ W^T (+ bias); x [..., K] with contiguous rows, W [N, K]."""
+    _gpu_bf16(x, weight)
+    k = x.shape[-1]
+    n = weight.shape[0]
+    assert weight.is_contiguous() and weight.shape[1] == k
+    x2 = x.reshape(-1, k)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    m = x2.shape[0]
+    y = torch.empty(m, n, dtype=BF16, device=x.device)
+    _hip.call("nvh_gemm_bf16_nt", x2.data_ptr(), x2.stride(0), weight.data_ptr(), _p(bias), y.data_ptr(), n, m, n, k, 1,
+              0, _stream())
+    return y.view(*x.shape[:-1], n)
+
+
+def linear_splitk(x: torch.Tensor, weight: torch.Tensor, split_k: int) -> torch.Tensor:
+    """fp32 partial slabs [split_k, M, N]; the consumer (add_rmsnorm / splitk_reduce) sums them."""
+    _gpu_bf16(x, weight)
+    k = x.shape[-1]
+    n = weight.shape[0]
+    x2 = x.reshape(-1, k)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    m = x2.shape[0]
+    ws = torch.empty(split_k, m, n, dtype=torch.float32, device=x.device)
+    _hip.call("nvh_gemm_bf16_nt", x2.data_ptr(), x2.stride(0), weight.data_ptr(), 0, 0, n, m, n, k, split_k,
+              ws.data_ptr(), _stream())
+    return ws
+
+
+def splitk_reduce(partials: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    s, m, n = partials.shape
+    y = torch.empty(m, n, dtype=BF16, device=partials.device)
+    _hip.call("nvh_splitk_reduce", partials.data_ptr(), s, _p(bias), y.data_ptr(), n, m, n, _stream())
+    return y
+
+
+# ---------------------------------------------------------------- attention
+def attn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, scale: float, block_tables=None) -> torch.Tensor:
+    """q [T,Hq,128]; (k, v) packed [Tk,Hkv,128] or page pools [P,256,Hkv,128] with block_tables [B,W] int32."""
+    _gpu_bf16(q, k, v)
+    t, hq, d = q.shape
+    assert q.stride(2) == 1 and q.stride(1) == d
+    if block_tables is None:
+        hkv = k.shape[1]
+        assert k.stride(2) == 1 and k.stride(1) == d and v.stride(1) == d and k.stride(0) == v.stride(0)
+        kv_stride, tbl, tbl_stride = k.stride(0), 0, 0
+    else:
+        hkv = k.shape[2]
+        assert k.is_contiguous() and v.is_contiguous() and k.shape[1] == KV_PAGE
+        assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+        kv_stride, tbl, tbl_stride = hkv * d, block_tables.data_ptr(), block_tables.stride(0)
+    out = torch.empty(t, hq, d, dtype=BF16, device=q.device)
+    _hip.call("nvh_attn_varlen", q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), kv_stride,
+              cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), tbl, tbl_stride, cu_seqlens_q.numel() - 1,
+              max_seqlen_q, t, hq, hkv, d, float(scale), out.data_ptr(), _stream())
+    return out
+
+
+def suggest_decode_splits(batch: int, num_kv_heads: int, max_context: int) -> int:
+    return _hip.lib().nvh_attn_decode_suggest_splits(batch, num_kv_heads, max_context)
+
+
+def attn_decode(q, k_cache, v_cache, context_lens, block_tables, scale: float, num_splits: int = 0,
+                max_context: int | None = None) -> torch.Tensor:
+    """q [B,Hq,128] (token stride free); caches [P,256,Hkv,128]; one query per sequence."""
+    _gpu_bf16(q, k_cache, v_cache)
+    b, hq, d = q.shape
+    hkv = k_cache.shape[2]
+    assert q.stride(2) == 1 and q.stride(1) == d and k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+    if num_splits <= 0:
+        mc = max_context if max_context is not None else block_tables.shape[1] * KV_PAGE
+        num_splits = suggest_decode_splits(b, hkv, mc)
+    out = torch.empty(b, hq, d, dtype=BF16, device=q.device)
+    ws = 0
+    if num_splits > 1:
+        nbytes = _hip.lib().nvh_attn_decode_workspace_bytes(b, hq, d, num_splits)
+        ws_t = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+        ws = ws_t.data_ptr()
+    _hip.call("nvh_attn_decode", q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
+              context_lens.data_ptr(), block_tables.data_ptr(), block_tables.stride(0), b, hq, hkv, d, float(scale),
+              out.data_ptr(), num_splits, ws, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- sampling
+def _logits_args(logits):
+    assert logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1
+    if logits.dtype == torch.float32:
+        return 1
+    if logits.dtype == BF16:
+        return 0
+    raise TypeError(f"logits dtype {logits.dtype} unsupported")
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    f = _logits_args(logits)
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    _hip.call("nvh_argmax", logits.data_ptr(), f, logits.stride(0), out.data_ptr(), logits.shape[0], logits.shape[1], _stream())
+    return out
+
+
+def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
+    f = _logits_args(logits)
+    assert temperatures.dtype == torch.float32 and temperatures.numel() == logits.shape[0]
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    _hip.call("nvh_sample", logits.data_ptr(), f, logits.stride(0), temperatures.data_ptr(), out.data_ptr(),
+              logits.shape[0], logits.shape[1], seed, offset, _stream())
+    return out
+
+
+def sample_with_noise(logits: torch.Tensor, temperatures: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    f = _logits_args(logits)
+    assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == logits.shape
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    _hip.call("nvh_sample_with_noise", logits.data_ptr(), f, logits.stride(0), temperatures.data_ptr(), noise.data_ptr(),
+              out.data_ptr(), logits.shape[0], logits.shape[1], _stream())
+    return out

@@ -1,0 +1,376 @@
+"""Parity of every C-ABI operator (HIP, gfx950) against the CPU oracle on the same seeded
+inputs and against the golden vectors produced by the reference modules.
+
+Stated tolerances
+  * copies / gathers / argmax / slot arithmetic: bit-exact;
+  * RoPE: bit-exact (same fp32 op order, table built on the host);
+  * RMSNorm family, SiLU*mul: <= 2 bf16 ulp (two roundings: a 1-ulp flip of the first can move the
+    second) on <= 1 % of elements (reduction order / expf ulp);
+  * GEMM: |err| <= 2^-7*|ref| + 2e-3*max|ref| (one bf16 rounding of an fp32 sum whose accumulation
+    order differs; near-zero outputs are bounded absolutely), and <= 3 % of elements differ at all;
+  * attention: |err| <= 1.5e-2 + 2e-2*|ref| (bf16 P in the PV product, exp2 vs exp).
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import bf16_ulp_diff
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nanovllm import _hip, ops as o
+    _hip.check(_hip.lib().nvh_device_check(0), "nvh_device_check")
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*s, seed=0, scale=1.0, dtype=BF):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*s, generator=g) * scale).to(dtype)
+
+
+def assert_ulp(got, ref, max_ulp=2, max_frac=0.01):
+    got = got.cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    d = bf16_ulp_diff(got, ref)
+    frac = float((d > 0).float().mean())
+    assert int(d.max()) <= max_ulp and frac <= max_frac, f"max ulp {int(d.max())}, frac differing {frac:.4f}"
+
+
+def assert_gemm(got, ref, max_frac=0.03):
+    got = got.cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    g, r = got.float(), ref.float()
+    err = (g - r).abs()
+    tol = 2.0 ** -7 * r.abs() + 2e-3 * float(r.abs().max())
+    frac = float((got != ref).float().mean())
+    assert bool((err <= tol).all()) and frac <= max_frac, f"max err {float(err.max()):.4g}, frac differing {frac:.4f}"
+
+
+def assert_exact(got, ref):
+    got = got.cpu()
+    assert got.shape == ref.shape and torch.equal(got, ref), f"mismatch: {int((got != ref).sum())} elements"
+
+
+def assert_close(got, ref, atol, rtol):
+    got = got.cpu().float()
+    ref = ref.float()
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bool(bad.any()), f"max err {float(err.max()):.4g}, {int(bad.sum())} / {bad.numel()} outside tolerance"
+
+
+# ------------------------------------------------------------------ golden vectors (reference modules)
+def test_golden_rmsnorm(ops, f1):
+    for tag in ("rms_2d", "rms_heads"):
+        y = ops.rmsnorm(dev(f1.bf(tag + "_x")), dev(f1.bf(tag + "_w")), 1e-6)
+        assert_ulp(y, f1.bf(tag + "_y"))
+    res = dev(f1.bf("addrms_r").clone())
+    y, res2 = ops.add_rmsnorm(dev(f1.bf("addrms_x")), res, dev(f1.bf("addrms_w")), 1e-6)
+    assert_ulp(y, f1.bf("addrms_y"))
+    assert_exact(res2, f1.bf("addrms_res"))
+
+
+def test_golden_rope_bit_exact(ops, f1):
+    table = R.rope_table(128, 40960, 1e6).squeeze(1).contiguous()
+    q, k = dev(f1.bf("rope_q").clone()), dev(f1.bf("rope_k").clone())
+    ops.rope_(dev(f1.t("rope_pos")), q, k, dev(table))
+    assert_exact(q, f1.bf("rope_qo"))
+    assert_exact(k, f1.bf("rope_ko"))
+
+
+def test_golden_silu_linear_embedding(ops, f1):
+    assert_ulp(ops.silu_mul(dev(f1.bf("silu_x"))), f1.bf("silu_y"))
+    for tag in ("lin", "lin_bias"):
+        b = dev(f1.bf(tag + "_b")) if tag + "_b" in f1 else None
+        y = ops.linear(dev(f1.bf(tag + "_x")), dev(f1.bf(tag + "_w")), b)
+        assert_gemm(y, f1.bf(tag + "_y"))
+    assert_exact(ops.embedding(dev(f1.t("emb_ids")), dev(f1.bf("emb_w"))), f1.bf("emb_y"))
+    hidden, cu = dev(f1.bf("head_hidden")), dev(f1.t("head_cu"))
+    need = dev(f1.t("head_subset_need"))
+    rows = ops.gather_last_rows(hidden, cu, need, 2)
+    assert_exact(rows, R.last_token_rows(f1.bf("head_hidden"), f1.t("head_cu"), f1.t("head_subset_need")))
+    rows_all = ops.gather_last_rows(hidden, cu, None, 3)
+    assert_exact(rows_all, R.last_token_rows(f1.bf("head_hidden"), f1.t("head_cu"), f1.t("head_empty_need")))
+
+
+def test_golden_sampler(ops, f1):
+    tok = ops.sample_with_noise(dev(f1.t("samp_logits")), dev(f1.t("samp_temps")), dev(f1.t("samp_noise")))
+    assert_exact(tok, f1.t("samp_tok"))
+
+
+# ------------------------------------------------------------------ seeded inputs vs the oracle
+@pytest.mark.parametrize("rows,dim", [(1, 1024), (7, 1024), (1024, 1024), (33, 5120), (5, 256), (64, 128), (3, 8192)])
+def test_rmsnorm_shapes(ops, rows, dim):
+    x, w = rnd(rows, dim, seed=1, scale=2.0), (rnd(dim, seed=2).float() * 0.1 + 1).to(BF)
+    assert_ulp(ops.rmsnorm(dev(x), dev(w), 1e-6), R.rms_norm(x, w, 1e-6))
+    r = rnd(rows, dim, seed=3, scale=2.0)
+    yr, nr = R.add_rms_norm(x, r, w, 1e-6)
+    rd = dev(r.clone())
+    y, res = ops.add_rmsnorm(dev(x), rd, dev(w), 1e-6)
+    assert_ulp(y, yr)
+    assert_exact(res, nr)
+    assert res.data_ptr() == rd.data_ptr()        # residual updated in place
+
+
+def test_add_rmsnorm_from_splitk_slabs(ops):
+    m, n, k = 5, 1024, 2048
+    x, w = rnd(m, k, seed=4), rnd(n, k, seed=5, scale=0.05)
+    gamma = (rnd(n, seed=6).float() * 0.1 + 1).to(BF)
+    res = rnd(m, n, seed=7)
+    slabs = ops.linear_splitk(dev(x), dev(w), 4)
+    assert slabs.shape == (4, m, n)
+    y_lin = R.linear(x, w)
+    assert_gemm(ops.splitk_reduce(slabs), y_lin)
+    y, nres = ops.add_rmsnorm(None, dev(res.clone()), dev(gamma), 1e-6, partials=slabs)
+    yr, rr = R.add_rms_norm(y_lin, res, gamma, 1e-6)
+    assert_close(y, yr, 2e-2, 2e-2)
+    assert_close(nres, rr, 2e-2, 2e-2)
+
+
+def test_store_kvcache_strided_and_skips(ops):
+    t, hq, hkv, d = 37, 4, 2, 128
+    qkv = rnd(t, (hq + 2 * hkv) * d, seed=8)
+    q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    k, v = k.view(t, hkv, d), v.view(t, hkv, d)
+    g = torch.Generator().manual_seed(9)
+    slots = torch.randperm(3 * 256, generator=g)[:t].to(torch.int32)
+    slots[5] = -1
+    slots[36] = -1
+    kc, vc = rnd(3, 256, hkv, d, seed=10), rnd(3, 256, hkv, d, seed=11)
+    kr, vr = kc.clone(), vc.clone()
+    R.store_kvcache(k, v, kr, vr, slots)
+    qkv_d = dev(qkv)
+    _, kd, vd = qkv_d.split([hq * d, hkv * d, hkv * d], dim=-1)
+    kcd, vcd = dev(kc), dev(vc)
+    ops.store_kvcache(kd.view(t, hkv, d), vd.view(t, hkv, d), kcd, vcd, dev(slots))
+    assert_exact(kcd, kr)
+    assert_exact(vcd, vr)
+
+
+def test_fused_qknorm_rope_store_equals_sequence(ops):
+    t, hq, hkv, d = 19, 16, 8, 128
+    qkv = rnd(t, (hq + 2 * hkv) * d, seed=12, scale=1.5)
+    qw, kw = (rnd(d, seed=13).float() * 0.2 + 1).to(BF), (rnd(d, seed=14).float() * 0.2 + 1).to(BF)
+    pos = torch.tensor([0, 1, 2, 255, 256, 257, 4095, 40959] + list(range(100, 111)), dtype=torch.int64)
+    table = R.rope_table(128, 40960, 1e6)
+    slots = torch.arange(t, dtype=torch.int32) * 3 + 1
+    slots[4] = -1
+    q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    qn = R.rms_norm(q.reshape(t, hq, d), qw, 1e-6)
+    kn = R.rms_norm(k.reshape(t, hkv, d), kw, 1e-6)
+    qr, kr = R.rope(pos, qn, kn, table)
+    kc, vc = torch.zeros(1, 256, hkv, d, dtype=BF), torch.zeros(1, 256, hkv, d, dtype=BF)
+    R.store_kvcache(kr, v.reshape(t, hkv, d), kc, vc, slots)
+
+    qkv_d = dev(qkv.clone())
+    kcd, vcd = dev(torch.zeros_like(kc)), dev(torch.zeros_like(vc))
+    ops.qknorm_rope_store_(qkv_d, hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), dev(table.squeeze(1).contiguous()), kcd, vcd, dev(slots))
+    qd, kd, vd = qkv_d.cpu().split([hq * d, hkv * d, hkv * d], dim=-1)
+    assert_ulp(qd.reshape(t, hq, d), qr, max_ulp=1, max_frac=0.01)
+    assert_ulp(kd.reshape(t, hkv, d), kr, max_ulp=1, max_frac=0.01)
+    assert_exact(vd, v)                                   # v untouched
+    assert_exact(vcd, vc)                                 # v scatter is a pure copy
+    assert_exact(kcd[0][slots[slots >= 0].long()], kd.reshape(t, hkv, d)[slots >= 0])   # cache rows == rotated k rows
+    # same arithmetic as the three separate entry points
+    qkv_s = dev(qkv.clone())
+    qs, ks, vs = qkv_s.split([hq * d, hkv * d, hkv * d], dim=-1)
+    qn_d = ops.rmsnorm(qs.reshape(t, hq, d), dev(qw), 1e-6)
+    kn_d = ops.rmsnorm(ks.reshape(t, hkv, d), dev(kw), 1e-6)
+    ops.rope_(dev(pos), qn_d, kn_d, dev(table.squeeze(1).contiguous()))
+    assert_exact(qn_d, qd.reshape(t, hq, d))
+    assert_exact(kn_d, kd.reshape(t, hkv, d))
+
+
+def test_silu_mul_shapes(ops):
+    for rows, inter in ((1, 3072), (300, 3072), (17, 512)):
+        x = rnd(rows, 2 * inter, seed=15, scale=3.0)
+        assert_ulp(ops.silu_mul(dev(x)), R.silu_mul(x))
+
+
+def test_embedding_vocab_parallel(ops):
+    table = rnd(64, 256, seed=16)
+    ids = torch.tensor([0, 63, 17, 40, 31, 32], dtype=torch.int64)
+    for ws in (1, 2, 4):
+        n = 64 // ws
+        for rk in range(ws):
+            shard = table[rk * n:(rk + 1) * n].contiguous()
+            got = ops.embedding(dev(ids), dev(shard), vocab_start=rk * n)
+            assert_exact(got, R.embedding(ids, shard, vocab_start=rk * n, tp_size=ws))
+
+
+GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024), (33, 1024, 3072), (64, 1024, 256),
+               (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256)]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
+def test_gemm_vs_oracle(ops, m, n, k):
+    x, w = rnd(m, k, seed=m + n), rnd(n, k, seed=k + 1, scale=0.05)
+    ref = R.linear(x, w)
+    y = ops.linear(dev(x), dev(w))
+    assert_gemm(y, ref)
+
+
+def test_gemm_bias_strided_input_and_splitk(ops):
+    m, n, k = 45, 1024, 2048
+    x_wide = rnd(m, k + 64, seed=20)
+    x = x_wide[:, :k]                                   # row stride k+64
+    w, b = rnd(n, k, seed=21, scale=0.05), rnd(n, seed=22)
+    ref = R.linear(x, w, b)
+    assert_gemm(ops.linear(dev(x_wide)[:, :k], dev(w), dev(b)), ref)
+    for s in (2, 3, 8):
+        slabs = ops.linear_splitk(dev(x_wide)[:, :k], dev(w), s)
+        assert_gemm(ops.splitk_reduce(slabs, dev(b)), ref)
+
+
+def _paged_case(seed, lens_q, lens_k, hq, hkv, num_pages=40):
+    """Random q for the new tokens and a cache holding every sequence's lk keys in shuffled pages."""
+    g = torch.Generator().manual_seed(seed)
+    d = 128
+    b = len(lens_q)
+    kc, vc = rnd(num_pages, 256, hkv, d, seed=seed + 1), rnd(num_pages, 256, hkv, d, seed=seed + 2)
+    perm = torch.randperm(num_pages, generator=g).tolist()
+    tables, used = [], 0
+    for lk in lens_k:
+        nb = (lk + 255) // 256
+        tables.append(perm[used:used + nb])
+        used += nb
+    assert used <= num_pages
+    width = max(1, max(len(t) for t in tables))
+    bt = torch.tensor([t + [-1] * (width - len(t)) for t in tables], dtype=torch.int32)
+    q = rnd(sum(lens_q), hq, d, seed=seed + 3)
+    cu_q = torch.tensor([0] + list(torch.tensor(lens_q).cumsum(0)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(torch.tensor(lens_k).cumsum(0)), dtype=torch.int32)
+    return q, kc, vc, bt, cu_q, cu_k
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (8, 2), (10, 2), (8, 1)])
+@pytest.mark.parametrize("splits", [1, 0, 5])
+def test_attn_decode_vs_oracle(ops, hq, hkv, splits):
+    lens_k = [1, 255, 256, 257, 1000, 64, 0, 700]
+    b = len(lens_k)
+    q, kc, vc, bt, _, _ = _paged_case(30 + hq, [1] * b, lens_k, hq, hkv)
+    ctx = torch.tensor(lens_k, dtype=torch.int32)
+    scale = 128 ** -0.5
+    ref = R.attention_decode(q, kc, vc, ctx, bt, scale)
+    got = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=splits)
+    assert_close(got, ref, 1.5e-2, 2e-2)
+    assert float(got[6].abs().max()) == 0.0             # padded row (length 0) -> zeros
+
+
+def test_attn_decode_strided_q_long_context(ops):
+    hq, hkv, d = 16, 8, 128
+    lens_k = [8192, 3000]
+    q, kc, vc, bt, _, _ = _paged_case(41, [1, 1], lens_k, hq, hkv, num_pages=48)
+    qkv = torch.zeros(2, (hq + 2 * hkv) * d, dtype=BF)
+    qkv[:, :hq * d] = q.reshape(2, -1)
+    ctx = torch.tensor(lens_k, dtype=torch.int32)
+    scale = d ** -0.5
+    ref = R.attention_decode(q, kc, vc, ctx, bt, scale)
+    qv = dev(qkv)[:, :hq * d].view(2, hq, d)
+    for splits in (1, 16, 64):
+        got = ops.attn_decode(qv, dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=splits)
+        assert_close(got, ref, 1.5e-2, 2e-2)
+
+
+VARLEN_CASES = [
+    # (lens_q, lens_k): fresh prefill, chunk crossing pages, prefix hit, decode rows in a mixed batch
+    ([5, 1, 9], [5, 1, 9]),
+    ([64, 65, 31, 32, 33], [64, 65, 31, 32, 33]),
+    ([300], [300]),
+    ([44, 1, 257, 1], [300, 700, 513, 1]),
+    ([1024], [2048]),
+    ([100, 3], [100 + 256, 259]),
+]
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 4), (8, 2), (10, 2), (8, 1)])
+@pytest.mark.parametrize("case", range(len(VARLEN_CASES)))
+def test_attn_varlen_paged_vs_oracle(ops, hq, hkv, case):
+    lens_q, lens_k = VARLEN_CASES[case]
+    q, kc, vc, bt, cu_q, cu_k = _paged_case(50 + case, lens_q, lens_k, hq, hkv)
+    scale = 128 ** -0.5
+    ref = R.attention_varlen(q, None, None, cu_q, cu_k, scale, kc, vc, bt)
+    got = ops.attn_varlen(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(lens_q), scale, dev(bt))
+    assert_close(got, ref, 1.5e-2, 2e-2)
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1)])
+def test_attn_varlen_packed_strided_vs_oracle(ops, hq, hkv):
+    """Mode without a block table: K/V are the packed new tokens, given as strided views of qkv."""
+    d = 128
+    lens = [70, 1, 200, 33]
+    t = sum(lens)
+    qkv = rnd(t, (hq + 2 * hkv) * d, seed=60)
+    q, k, v = qkv.split([hq * d, hkv * d, hkv * d], dim=-1)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    scale = d ** -0.5
+    ref = R.attention_varlen(q.reshape(t, hq, d), k.reshape(t, hkv, d), v.reshape(t, hkv, d), cu, cu, scale)
+    qd, kd, vd = dev(qkv).split([hq * d, hkv * d, hkv * d], dim=-1)
+    got = ops.attn_varlen(qd.view(t, hq, d), kd.view(t, hkv, d), vd.view(t, hkv, d), dev(cu), dev(cu), max(lens), scale)
+    assert_close(got, ref, 1.5e-2, 2e-2)
+
+
+def test_attn_integer_exact_layout_check(ops):
+    """Small-integer Q/K/V with an ASYMMETRIC V: a swapped fragment map cannot pass.
+    One key per query is made dominant so softmax is one-hot up to e^-30 and the
+    output must equal that V row exactly."""
+    hq, hkv, d = 2, 1, 128
+    lq = lk = 96
+    k = torch.zeros(lk, hkv, d)
+    q = torch.zeros(lq, hq, d)
+    for j in range(lk):
+        k[j, 0, j % d] = 8.0
+    target = [(i * 7) % (i + 1) for i in range(lq)]          # any key <= i
+    for i in range(lq):
+        for h in range(hq):
+            tj = target[i] if h == 0 else (i - target[i])
+            q[i, h, tj % d] = 8.0 * math.sqrt(d) / 2
+    v = (torch.arange(lk * d).reshape(lk, 1, d) % 251).float() - 125
+    cu = torch.tensor([0, lq], dtype=torch.int32)
+    out = ops.attn_varlen(dev(q.to(BF)), dev(k.to(BF)), dev(v.to(BF)), dev(cu), dev(cu), lq, d ** -0.5).cpu().float()
+    for i in range(lq):
+        # the other keys leak e^-32 each: far below half a bf16 ulp of any non-zero integer
+        assert torch.allclose(out[i, 0], v[target[i], 0], rtol=0, atol=1e-6), f"query {i} head 0"
+        assert torch.allclose(out[i, 1], v[i - target[i], 0], rtol=0, atol=1e-6), f"query {i} head 1"
+
+
+def test_argmax_and_sampling(ops):
+    g = torch.Generator().manual_seed(70)
+    logits = torch.randn(6, 151936, generator=g).to(BF)
+    logits[2, 777] = logits[2, 5000] = 9.0                   # tie -> lowest index
+    assert_exact(ops.argmax(dev(logits)), R.greedy(logits))
+    lf = torch.randn(3, 1000, generator=g) * 2
+    assert_exact(ops.argmax(dev(lf)), R.greedy(lf))
+    # explicit noise: identical to the oracle's deterministic form
+    temps = torch.tensor([0.6, 1.0, 2.0])
+    noise = torch.empty(3, 1000).exponential_(1, generator=g)
+    assert_exact(ops.sample_with_noise(dev(lf), dev(temps), dev(noise)), R.sample_with_noise(lf, temps, noise))
+    # temperature -> 0 collapses to greedy
+    cold = torch.full((6,), 1e-9)
+    untied = logits.clone()
+    untied[2, 5000] = 8.0                                    # an exact tie is split by the noise, as in the reference
+    assert_exact(ops.sample(dev(untied), dev(cold), seed=1, offset=0), R.greedy(untied))
+    # distribution: chi-square of 20000 draws from a 6-way distribution, temperature 0.7
+    base = torch.tensor([2.0, 1.0, 0.5, 0.0, -1.0, -3.0])
+    n = 20000
+    rows = base.repeat(n, 1).contiguous()
+    t = torch.full((n,), 0.7)
+    draws = ops.sample(dev(rows), dev(t), seed=1234, offset=5).cpu()
+    p = torch.softmax(base / 0.7, 0)
+    counts = torch.bincount(draws, minlength=6).float()
+    chi2 = float(((counts - n * p) ** 2 / (n * p)).sum())
+    assert chi2 < 25.0, chi2                                  # 5 dof: P(chi2 > 25) ~ 1e-4
+    again = ops.sample(dev(rows), dev(t), seed=1234, offset=5).cpu()
+    assert torch.equal(draws, again)                          # counter-based: reproducible
+    other = ops.sample(dev(rows), dev(t), seed=1234, offset=6).cpu()
+    assert not torch.equal(draws, other)
