@@ -1,0 +1,397 @@
+"""Model runner: turns the scheduler's sequence list into one forward pass on an MI355X.
+
+Same contract as the reference's engine/model_runner.py:49-715 -
+``ModelRunner(config, rank, event)``, ``call(method, *args)`` with methods ``"run"`` and
+``"exit"``, ``run(seqs) -> (token_ids | None, seq_need_compute_logits)``, side effect
+``config.num_kvcache_blocks`` - with a different inside:
+
+  * batch flattening is vectorised numpy over per-sequence scalars (no per-token Python), and all
+    step metadata crosses PCIe in ONE pinned-buffer copy instead of eight;
+  * the forward is the gfx950 kernel path (nanovllm.ops); one-token-per-sequence steps replay a
+    hipGraph whose input buffers are the copy's destination;
+  * a step in which no sequence finishes its prompt (a lone chunked prefill) returns ``([], need)``
+    instead of tripping the scheduler's length assertion (the reference samples every sequence
+    there and fails in postprocess);
+  * an already initialised process group (torchrun, one rank per GPU) is used as is: every rank
+    then calls ``run`` with the same sequences and no shared-memory control plane is needed.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from multiprocessing.shared_memory import SharedMemory
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import _hip
+from ..config import Config, model_dtype
+from ..layers.sampler import Sampler
+from ..models.qwen3 import Qwen3ForCausalLM
+from ..utils.context import get_context, reset_context, set_context
+from ..utils.loader import has_checkpoint, load_model, load_tensors, synthetic_tensors
+from .sequence import Sequence
+
+SHM_NAME = "nanovllm"
+SHM_BYTES = 2 ** 20
+
+
+# ------------------------------------------------------------------------------------------
+# host-side batch flattening (device independent; unit-tested on CPU)
+# ------------------------------------------------------------------------------------------
+def flatten_batch(seqs, block_size: int = 256) -> dict:
+    """Per-step tensors of reference model_runner.py:438-495 as numpy arrays.
+
+    input_ids / positions int64 [T]; cu_seqlens_q / cu_seqlens_k int32 [B+1]; slot_mapping int32
+    (one entry per new token of every sequence that owns a block table); context_lens int32 [B];
+    need int32 [B'] (sequences whose scheduled tokens reach their end and that own a block table);
+    block_tables int32 [B, W] padded with -1, or None when no sequence has cached keys.
+    """
+    nseq = len(seqs)
+    cached = np.fromiter((s.num_cached_tokens for s in seqs), dtype=np.int64, count=nseq)
+    new = np.fromiter((s.num_new_tokens for s in seqs), dtype=np.int64, count=nseq)
+    total = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=nseq)
+    ntab = np.fromiter((len(s.block_table) for s in seqs), dtype=np.int64, count=nseq)
+    ctx = cached + new
+    cu_q = np.zeros(nseq + 1, dtype=np.int32)
+    cu_k = np.zeros(nseq + 1, dtype=np.int32)
+    np.cumsum(new, out=cu_q[1:])
+    np.cumsum(ctx, out=cu_k[1:])
+    t = int(cu_q[-1])
+    parts = [s[int(c):int(e)] for s, c, e in zip(seqs, cached, ctx)]
+    input_ids = np.fromiter((tok for part in parts for tok in part), dtype=np.int64, count=t) if t else np.zeros(0, np.int64)
+    seq_of_tok = np.repeat(np.arange(nseq), new)
+    positions = np.arange(t, dtype=np.int64) - np.repeat(cu_q[:-1].astype(np.int64), new) + np.repeat(cached, new)
+    need = np.nonzero((total == ctx) & (ntab > 0))[0].astype(np.int32)
+    width = int(ntab.max()) if nseq else 0
+    tables = None
+    if width:
+        tables = np.full((nseq, width), -1, dtype=np.int32)
+        for i, s in enumerate(seqs):
+            tables[i, :len(s.block_table)] = s.block_table
+        has = ntab[seq_of_tok] > 0
+        pos_h, seq_h = positions[has], seq_of_tok[has]
+        slot_mapping = (tables[seq_h, pos_h // block_size].astype(np.int64) * block_size + pos_h % block_size).astype(np.int32)
+    else:
+        slot_mapping = np.zeros(0, dtype=np.int32)
+    return dict(input_ids=input_ids, positions=positions, cu_seqlens_q=cu_q, cu_seqlens_k=cu_k,
+                max_seqlen_q=int(new.max()) if nseq else 0, max_seqlen_k=int(ctx.max()) if nseq else 0,
+                slot_mapping=slot_mapping, context_lens=ctx.astype(np.int32), need=need,
+                block_tables=tables if int(cu_k[-1]) > int(cu_q[-1]) else None)
+
+
+class _Staging:
+    """One pinned host buffer + one device buffer per step: named arrays are packed back to back
+    (16-byte aligned), copied with a single async H2D, and handed out as typed device views."""
+
+    def __init__(self, device):
+        self.device = device
+        self.host = torch.empty(1 << 16, dtype=torch.uint8, device="cpu", pin_memory=device.type == "cuda")
+        self.event = torch.cuda.Event() if device.type == "cuda" else None
+
+    def upload(self, arrays: dict) -> dict:
+        offs, n = {}, 0
+        for name, a in arrays.items():
+            offs[name] = n
+            n += (a.nbytes + 15) & ~15
+        n = max(n, 16)
+        if self.host.numel() < n:
+            self.host = torch.empty(max(n, 2 * self.host.numel()), dtype=torch.uint8, device="cpu",
+                                    pin_memory=self.device.type == "cuda")
+        if self.event is not None:
+            self.event.synchronize()            # the previous step's copy has left the buffer
+        hnp = self.host.numpy()
+        for name, a in arrays.items():
+            hnp[offs[name]:offs[name] + a.nbytes] = a.reshape(-1).view(np.uint8)
+        dev = torch.empty(n, dtype=torch.uint8, device=self.device)
+        dev.copy_(self.host[:n], non_blocking=True)
+        if self.event is not None:
+            self.event.record()
+        out = {}
+        for name, a in arrays.items():
+            view = dev[offs[name]:offs[name] + a.nbytes].view(_TORCH_DTYPE[a.dtype.type])
+            out[name] = view.view(a.shape)
+        return out
+
+
+_TORCH_DTYPE = {np.int64: torch.int64, np.int32: torch.int32, np.float32: torch.float32}
+
+
+class ModelRunner:
+    def __init__(self, config: Config, rank: int, event):
+        self.config = config
+        hf = config.hf_config
+        self.block_size = config.kvcache_block_size
+        self.enforce_eager = config.enforce_eager
+        self.world_size = config.tensor_parallel_size
+        self.rank = rank
+        self.event = event
+        self.external_group = dist.is_initialized()
+        self.shm = None
+
+        if self.external_group:
+            assert dist.get_world_size() == self.world_size and dist.get_rank() == rank
+        elif self.world_size > 1:
+            port = int(os.environ.get("NANOVLLM_PORT", "2333"))
+            dist.init_process_group("nccl", f"tcp://127.0.0.1:{port}", world_size=self.world_size, rank=rank)
+        device_index = int(os.environ.get("LOCAL_RANK", rank)) if self.external_group else rank
+        torch.cuda.set_device(device_index)
+        self.device = torch.device("cuda", device_index)
+        _hip.check(_hip.lib().nvh_device_check(device_index), "nvh_device_check")
+
+        dtype = model_dtype(hf)
+        if dtype != torch.bfloat16:
+            raise _hip.HipError(f"model dtype {dtype} unsupported: the kernel path is bf16 only")
+        prev_dtype = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        torch.set_default_device(self.device)
+        try:
+            self.model = Qwen3ForCausalLM(hf)
+            if has_checkpoint(config.model):
+                load_model(self.model, config.model)
+            else:
+                load_tensors(self.model, synthetic_tensors(hf, seed=0, device=self.device, dtype=dtype))
+            self.sampler = Sampler()
+            self.staging = _Staging(self.device)
+            self.graphs, self.graph_bs = {}, []
+            self.warmup_model()
+            self.allocate_kv_cache()
+            if not self.enforce_eager:
+                self.capture_graphs()
+        finally:
+            torch.set_default_device("cpu")
+            torch.set_default_dtype(prev_dtype)
+
+        if self.world_size > 1 and not self.external_group:
+            if rank == 0:
+                try:
+                    stale = SharedMemory(name=SHM_NAME, create=False)
+                    stale.close()
+                    stale.unlink()
+                except FileNotFoundError:
+                    pass
+                self.shm = SharedMemory(name=SHM_NAME, create=True, size=SHM_BYTES)
+                dist.barrier()
+            else:
+                dist.barrier()
+                self.shm = SharedMemory(name=SHM_NAME)
+                self.loop()
+
+    # -------------------------------------------------------------- control plane (tp > 1)
+    def exit(self):
+        if self.shm is not None:
+            self.shm.close()
+            dist.barrier()
+            if self.rank == 0:
+                self.shm.unlink()
+        self.graphs = {}
+        torch.cuda.synchronize()
+        if dist.is_initialized() and not self.external_group:
+            dist.destroy_process_group()
+
+    def loop(self):
+        while True:
+            method_name, args = self.read_shm()
+            self.call(method_name, *args)
+            if method_name == "exit":
+                break
+
+    def read_shm(self):
+        assert self.world_size > 1 and self.rank > 0
+        self.event.wait()
+        n = int.from_bytes(self.shm.buf[0:4], "little")
+        method_name, *args = pickle.loads(self.shm.buf[4:n + 4])
+        self.event.clear()
+        return method_name, args
+
+    def write_shm(self, method_name, *args):
+        assert self.world_size > 1 and self.rank == 0
+        data = pickle.dumps([method_name, *args])
+        n = len(data)
+        if n + 4 > SHM_BYTES:
+            raise RuntimeError(f"control message of {n} bytes exceeds the {SHM_BYTES}-byte shared segment")
+        self.shm.buf[0:4] = n.to_bytes(4, "little")
+        self.shm.buf[4:n + 4] = data
+        for event in self.event:
+            event.set()
+
+    def call(self, method_name, *args):
+        if self.shm is not None and self.rank == 0:
+            self.write_shm(method_name, *args)
+        return getattr(self, method_name)(*args)
+
+    # -------------------------------------------------------------- init-time passes
+    def warmup_model(self):
+        """One maximum-shape forward without a cache, to measure peak activation memory."""
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        cfg = self.config
+        num_seqs = max(min(cfg.max_num_batched_tokens // cfg.max_model_len, cfg.max_num_seqs), 1)
+        length = min(cfg.max_model_len, cfg.max_num_batched_tokens)
+        seqs = [Sequence([0] * length) for _ in range(num_seqs)]
+        for seq in seqs:
+            seq.num_new_tokens = length
+        self.run(seqs)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+    def kv_block_bytes(self) -> int:
+        hf = self.config.hf_config
+        num_kv_heads = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        return 2 * hf.num_hidden_layers * self.block_size * num_kv_heads * head_dim * 2
+
+    def allocate_kv_cache(self):
+        """KV pool [2, L, blocks, 256, Hkv/tp, D]; per-layer views are bound to the attention modules.
+        A positive ``config.num_kvcache_blocks`` is honoured (tests, benchmarks); otherwise the pool
+        takes what ``gpu_memory_utilization`` leaves after weights and peak activations."""
+        cfg, hf = self.config, self.config.hf_config
+        if cfg.num_kvcache_blocks <= 0:
+            free, total = torch.cuda.mem_get_info()
+            used = total - free
+            stats = torch.cuda.memory_stats()
+            peak, current = stats["allocated_bytes.all.peak"], stats["allocated_bytes.all.current"]
+            cfg.num_kvcache_blocks = int(total * cfg.gpu_memory_utilization - used - peak + current) // self.kv_block_bytes()
+        assert cfg.num_kvcache_blocks > 0
+        num_kv_heads = hf.num_key_value_heads // self.world_size
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        self.kv_cache = torch.zeros(2, hf.num_hidden_layers, cfg.num_kvcache_blocks, self.block_size, num_kv_heads, head_dim)
+        layer_id = 0
+        for module in self.model.modules():
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):
+                module.k_cache = self.kv_cache[0, layer_id]
+                module.v_cache = self.kv_cache[1, layer_id]
+                module.max_context = cfg.max_model_len
+                layer_id += 1
+
+    # -------------------------------------------------------------- per-step input
+    def prepare_model_input(self, seqs, fb: dict | None = None):
+        fb = fb if fb is not None else flatten_batch(seqs, self.block_size)
+        arrays = {k: fb[k] for k in ("input_ids", "positions", "cu_seqlens_q", "cu_seqlens_k", "slot_mapping",
+                                     "context_lens", "need")}
+        if fb["block_tables"] is not None:
+            arrays["block_tables"] = fb["block_tables"]
+        if self.rank == 0:
+            temps = np.fromiter((s.temperature for s in seqs), dtype=np.float32, count=len(seqs))
+            arrays["temperatures"] = temps[fb["need"]] if fb["need"].size else temps
+        d = self.staging.upload(arrays)
+        set_context(d["cu_seqlens_q"], d["cu_seqlens_k"], fb["max_seqlen_q"], fb["max_seqlen_k"], d["slot_mapping"],
+                    d["context_lens"], d.get("block_tables"), d["need"])
+        return d["input_ids"], d["positions"], d.get("temperatures"), fb
+
+    # -------------------------------------------------------------- forward
+    @torch.inference_mode()
+    def run_model(self, input_ids: torch.Tensor, positions: torch.Tensor):
+        return self.model.compute_logits(self.model(input_ids, positions))
+
+    def _graph_for(self, fb):
+        """The captured graph that fits this step, or None (eager)."""
+        bs = len(fb["context_lens"])
+        if (self.enforce_eager or not self.graphs or fb["block_tables"] is None or fb["max_seqlen_q"] != 1
+                or fb["input_ids"].size != bs or bs > self.graph_bs[-1]):
+            return None
+        return self.graphs[next(x for x in self.graph_bs if x >= bs)]
+
+    @torch.inference_mode()
+    def forward_logits(self, seqs):
+        """Everything of a step up to the sampler: (logits [B', V] | None, temperatures | None, need)
+        with ``need`` a HOST int32 tensor (indices into ``seqs`` of the rows of ``logits``).  logits is
+        None on ranks > 0 and when no sequence finishes its scheduled prompt in this step."""
+        fb = flatten_batch(seqs, self.block_size)
+        graph = self._graph_for(fb)
+        need_host = torch.from_numpy(fb["need"])
+        has_tables = any(len(s.block_table) for s in seqs)
+        skip_logits = fb["need"].size == 0 and has_tables
+        if graph is not None:
+            hidden, temps = graph.replay(fb, seqs, self.rank == 0)
+            logits = self.model.lm_head.forward_rows(hidden[:len(seqs)])
+        else:
+            input_ids, positions, temps, _ = self.prepare_model_input(seqs, fb)
+            hidden = self.model(input_ids, positions)
+            logits = None if skip_logits else self.model.compute_logits(hidden)
+        reset_context()
+        return logits, temps, need_host
+
+    @torch.inference_mode()
+    def run(self, seqs):
+        logits, temps, need_host = self.forward_logits(seqs)
+        token_ids = None
+        if self.rank == 0:
+            token_ids = [] if logits is None else self.sampler(logits, temps).tolist()
+        return token_ids, need_host
+
+    # -------------------------------------------------------------- hipGraph decode
+    @torch.inference_mode()
+    def capture_graphs(self):
+        cfg = self.config
+        max_bs = min(cfg.max_num_seqs, 512)
+        width = (cfg.max_model_len + self.block_size - 1) // self.block_size
+        self.graph_bs = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+        pool = None
+        for bs in reversed(self.graph_bs):
+            g = _DecodeGraph(self, bs, width, pool)
+            pool = g.pool
+            self.graphs[bs] = g
+        torch.cuda.synchronize()
+
+
+class _DecodeGraph:
+    """One captured forward for ``bs`` one-token sequences.  Its inputs live in ONE device buffer laid
+    out like the pinned staging buffer, so a step is: fill staging, one H2D copy, one graph launch.
+    Padding rows carry slot -1 (no KV store), context length 0 (attention writes zeros)."""
+
+    def __init__(self, runner: ModelRunner, bs: int, width: int, pool):
+        self.bs, self.width = bs, width
+        dev = runner.device
+        sizes = dict(input_ids=bs * 8, positions=bs * 8, slot_mapping=bs * 4, context_lens=bs * 4,
+                     block_tables=bs * width * 4, temperatures=bs * 4)
+        self.offs, n = {}, 0
+        for name, nbytes in sizes.items():
+            self.offs[name] = (n, nbytes)
+            n += (nbytes + 15) & ~15
+        self.host = torch.zeros(n, dtype=torch.uint8, device="cpu", pin_memory=True)
+        self.dev = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.event = torch.cuda.Event()
+        hv, dv = self._views(self.host), self._views(self.dev)
+        self.h = {k: v.numpy() for k, v in hv.items()}
+        self.d = dv
+        self.h["slot_mapping"][:] = -1
+        self.dev.copy_(self.host)
+        model = runner.model
+        set_context(slot_mapping=dv["slot_mapping"], context_lens=dv["context_lens"], block_tables=dv["block_tables"])
+        model(dv["input_ids"], dv["positions"])                       # warm-up (allocator, lazy module state)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool):
+            self.out = model(dv["input_ids"], dv["positions"])
+        self.pool = self.graph.pool()
+        reset_context()
+
+    def _views(self, buf):
+        bs, w = self.bs, self.width
+        def v(name, dtype, *shape):
+            o, nb = self.offs[name]
+            return buf[o:o + nb].view(dtype).view(*shape)
+        return dict(input_ids=v("input_ids", torch.int64, bs), positions=v("positions", torch.int64, bs),
+                    slot_mapping=v("slot_mapping", torch.int32, bs), context_lens=v("context_lens", torch.int32, bs),
+                    block_tables=v("block_tables", torch.int32, bs, w), temperatures=v("temperatures", torch.float32, bs))
+
+    def replay(self, fb, seqs, want_temps: bool):
+        n = len(seqs)
+        self.event.synchronize()
+        h = self.h
+        h["input_ids"][:n] = fb["input_ids"]
+        h["positions"][:n] = fb["positions"]
+        h["slot_mapping"][:n] = fb["slot_mapping"]
+        h["slot_mapping"][n:] = -1
+        h["context_lens"][:n] = fb["context_lens"]
+        h["context_lens"][n:] = 0
+        tb = fb["block_tables"]
+        h["block_tables"][:n, :tb.shape[1]] = tb
+        if want_temps:
+            h["temperatures"][:n] = np.fromiter((s.temperature for s in seqs), dtype=np.float32, count=n)
+        self.dev.copy_(self.host, non_blocking=True)
+        self.event.record()
+        self.graph.replay()
+        return self.out, (self.d["temperatures"][:n] if want_temps else None)

@@ -50,6 +50,10 @@ class ParallelLMHead(VocabParallelEmbedding):
             rows = ops.gather_last_rows(x, ctx.cu_seqlens_q, need, need.numel())
         else:
             rows = ops.gather_last_rows(x, ctx.cu_seqlens_q, None, ctx.cu_seqlens_q.numel() - 1)
+        return self.forward_rows(rows)
+
+    def forward_rows(self, rows: torch.Tensor):
+        """Logits of already selected hidden rows [B', H] (one-token-per-sequence steps skip the gather)."""
         logits = ops.linear(rows, self.weight.data)
         if self.tp_size > 1:
             parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None

@@ -15,12 +15,14 @@ class RMSNorm(nn.Module):
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(hidden_size), requires_grad=False)
 
-    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):
+    def forward(self, x, residual: torch.Tensor | None = None):
+        """x: tensor, or a SplitKOutput (unreduced projection; only with a residual)."""
+        slabs = getattr(x, "slabs", None)
         if residual is None:
+            if slabs is not None:
+                x = x.reduce()
             return ops.rmsnorm(x, self.weight.data, self.eps)
         # the residual stream is updated in place: new_residual aliases `residual`
+        if slabs is not None:
+            return ops.add_rmsnorm(None, residual, self.weight.data, self.eps, partials=slabs)
         return ops.add_rmsnorm(x, residual, self.weight.data, self.eps)
-
-    def forward_from_partials(self, partials: torch.Tensor, residual: torch.Tensor):
-        """Same as forward(x, residual) with x = bf16(sum of fp32 split-K slabs [S, rows, dim])."""
-        return ops.add_rmsnorm(None, residual, self.weight.data, self.eps, partials=partials)

@@ -20,6 +20,20 @@ from torch import nn
 from .. import ops
 
 
+class SplitKOutput:
+    """Unreduced result of a split-K projection: fp32 slabs [S, M, N] whose sum (rounded to bf16) is
+    the layer output.  RMSNorm.forward accepts it in place of x and sums the slabs in its own
+    prologue, which saves the separate reduction launch."""
+
+    __slots__ = ("slabs",)
+
+    def __init__(self, slabs: torch.Tensor):
+        self.slabs = slabs
+
+    def reduce(self) -> torch.Tensor:
+        return ops.splitk_reduce(self.slabs)
+
+
 def divide(numerator: int, denominator: int) -> int:
     assert numerator % denominator == 0
     return numerator // denominator
@@ -114,19 +128,20 @@ class QKVParallelLinear(ColumnParallelLinear):
 class RowParallelLinear(LinearBase):
     def __init__(self, input_size: int, output_size: int, bias: bool = False):
         super().__init__(divide(input_size, tp_world()), output_size, bias, 1)
+        # set by the model wiring when the consumer is an RMSNorm that can sum split-K slabs
+        self.defer_reduce = False
 
     def weight_loader(self, param: nn.Parameter, loaded_weight: torch.Tensor):
         cols = param.data.size(self.tp_dim)
         param.data.copy_(loaded_weight.narrow(self.tp_dim, self.tp_rank * cols, cols))
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor):
+        if self.defer_reduce and self.tp_size == 1 and self.bias is None:
+            m = x.numel() // x.shape[-1]
+            split_k = ops.suggest_split_k(m, self.weight.shape[0], self.weight.shape[1])
+            if split_k > 1:
+                return SplitKOutput(ops.linear_splitk(x, self.weight.data, split_k))
         y = ops.linear(x, self.weight.data, self._bias() if self.tp_rank == 0 else None)
         if self.tp_size > 1:
             dist.all_reduce(y)
         return y
-
-    def forward_partials(self, x: torch.Tensor, split_k: int) -> torch.Tensor:
-        """Single-rank, bias-free fast path: fp32 split-K slabs [S, M, N] for a consumer that sums
-        them (RMSNorm.forward_from_partials)."""
-        assert self.tp_size == 1 and self.bias is None
-        return ops.linear_splitk(x, self.weight.data, split_k)

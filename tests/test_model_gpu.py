@@ -1,0 +1,179 @@
+"""End-to-end parity of the HIP runner (tiny Qwen3, random weights) against
+  * golden logits / greedy ids produced by the REFERENCE model wiring (tests/golden/f2), and
+  * the CPU oracle on the same inputs,
+through ModelRunner.forward_logits (everything of a step except the random sampler).
+
+Tolerance: logits |err| <= 3e-2 + 2e-2*|ref| (bf16 activations through 2 layers); greedy token
+ids bit-exact.
+"""
+import pytest
+import torch
+
+from conftest import ROOT, TINY
+from oracle import ref_model as M
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+TINY_DIR = str(ROOT / "nano-vllm-v1_amd" / "model_configs" / "qwen3-tiny")
+
+
+def hf_named(weights, shape):
+    """Oracle weights (packed names) -> Hugging Face checkpoint names, so the per-parameter shard
+    loaders (q/k/v, gate/up) are what fills the model."""
+    for name, t in weights.items():
+        if name == "lm_head.weight":
+            continue
+        if "qkv_proj" in name:
+            q, k, v = t.split([shape.q_size, shape.kv_size, shape.kv_size])
+            for tag, part in (("q_proj", q), ("k_proj", k), ("v_proj", v)):
+                yield name.replace("qkv_proj", tag), part
+        elif "gate_up_proj" in name:
+            g, u = t.chunk(2)
+            yield name.replace("gate_up_proj", "gate_proj"), g
+            yield name.replace("gate_up_proj", "up_proj"), u
+        else:
+            yield name, t
+
+
+def make_runner(enforce_eager, num_blocks=12, **kw):
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+    from nanovllm.utils.loader import load_tensors
+    cfg = Config(TINY_DIR, max_num_batched_tokens=1024, max_num_seqs=8, max_model_len=2048,
+                 enforce_eager=enforce_eager, num_kvcache_blocks=num_blocks, chunked_prefill=True, **kw)
+    runner = ModelRunner(cfg, 0, [])
+    shape = M.ModelShape(**TINY)
+    weights = M.random_weights(shape, seed=0, std=0.05)
+    n = load_tensors(runner.model, hf_named(weights, shape))
+    assert n == 1 + 2 * 11 + 1
+    return runner, M.RefRunner(shape, weights, num_blocks)
+
+
+@pytest.fixture(scope="module")
+def eager():
+    r = make_runner(True)
+    yield r
+    r[0].exit()
+
+
+@pytest.fixture(scope="module")
+def graphed():
+    r = make_runner(False)
+    yield r
+    r[0].exit()
+
+
+def seq(tokens, cached=0, new=None, table=()):
+    from nanovllm.engine.sequence import Sequence
+    s = Sequence(list(tokens))
+    s.num_cached_tokens, s.num_new_tokens, s.block_table = cached, len(tokens) - cached if new is None else new, list(table)
+    return s
+
+
+def close(got, ref, atol=3e-2, rtol=2e-2):
+    got, ref = got.float().cpu(), ref.float()
+    err = (got - ref).abs()
+    assert bool((err <= atol + rtol * ref.abs()).all()), f"max err {float(err.max()):.4g}"
+
+
+def test_mode_w_ragged_batch_matches_reference(eager, f2):
+    runner, oracle = eager
+    lens, toks = f2.z["w_lens"].tolist(), f2.z["w_prompts"].tolist()
+    seqs, o = [], 0
+    for n in lens:
+        seqs.append(seq(toks[o:o + n]))
+        o += n
+    logits, _, need = runner.forward_logits(seqs)
+    assert need.numel() == 0 and logits.shape == (3, 1024)      # no block table: every sequence gets logits
+    close(logits, f2.bf("w_logits"))
+    assert torch.equal(logits.float().argmax(-1).cpu(), f2.bf("w_logits").float().argmax(-1))
+
+
+@pytest.mark.parametrize("which", ["eager", "graphed"])
+def test_chunked_paged_greedy_ids_bit_exact(which, request, f2):
+    runner, oracle = request.getfixturevalue(which)
+    runner.kv_cache.zero_()
+    prompt, blocks = f2.z["p_prompt"].tolist(), f2.z["p_blocks"].tolist()
+    s = seq(prompt, 0, 0)
+    logits = None
+    for chunk, n_need in zip((3, 256, 41), (0, 0, 1)):
+        s.num_new_tokens = chunk
+        ctx = s.num_cached_tokens + chunk
+        s.block_table = blocks[:(ctx + 255) // 256]
+        logits, _, need = runner.forward_logits([s])
+        assert need.numel() == n_need and (logits is None) == (n_need == 0)   # lone chunk: no logits, no crash
+        s.num_cached_tokens = ctx
+    ids, rows = [], []
+    for _ in range(6):
+        tok = int(logits.float().argmax(-1)[0])
+        ids.append(tok)
+        rows.append(logits[0].cpu())
+        s.append_token(tok)
+        s.num_new_tokens = 1
+        s.block_table = blocks[:(len(s) + 255) // 256]
+        logits, _, need = runner.forward_logits([s])
+        s.num_cached_tokens += 1
+    assert ids == f2.z["p_ids"].tolist()
+    close(torch.stack(rows), f2.bf("p_rows"))
+
+
+def test_mixed_batch_matches_reference_and_oracle(eager, f2):
+    """decode row + prefix-hit prefill + fresh prefill in one step (block tables shared)."""
+    runner, oracle = eager
+    runner.kv_cache.zero_()
+    oracle.kv.zero_()
+    prompt, blocks = f2.z["p_prompt"].tolist(), f2.z["p_blocks"].tolist()
+    ids = f2.z["p_ids"].tolist()
+    full = prompt + ids + [int(f2.z["m_last_s"][0])]
+    # rebuild the cache state: prefill everything but the last token in one go, on both sides
+    pre = full[:-1]
+    for r in (runner, oracle):
+        s0 = seq(pre, 0, len(pre), blocks[:(len(pre) + 255) // 256]) if r is runner else M.SeqState(list(pre), 0, len(pre), blocks[:(len(pre) + 255) // 256])
+        (r.forward_logits([s0]) if r is runner else r.run([s0]))
+    t2, t3 = f2.z["m_tok_s2"].tolist(), f2.z["m_tok_s3"].tolist()
+    tb = blocks[:(len(full) + 255) // 256]
+    batch = [seq(full, len(full) - 1, 1, tb), seq(t2, 256, 40, [7, 4]), seq(t3, 0, 17, [5])]
+    logits, _, need = runner.forward_logits(batch)
+    assert need.tolist() == f2.z["m_need"].tolist() == [0, 1, 2]
+    close(logits, f2.bf("m_logits"))
+    ob = [M.SeqState(list(full), len(full) - 1, 1, tb), M.SeqState(list(t2), 256, 40, [7, 4]), M.SeqState(list(t3), 0, 17, [5])]
+    ol, _ = oracle.run(ob)
+    close(logits, ol)
+    assert torch.equal(logits.float().argmax(-1).cpu(), ol.float().argmax(-1))
+
+
+def test_graph_replay_equals_eager_decode_batch(eager, graphed):
+    """Three sequences decoding together (graph bucket 4, one padded row) vs the eager path."""
+    g = torch.Generator().manual_seed(11)
+    prompts = [torch.randint(0, 1024, (n,), generator=g).tolist() for n in (5, 300, 257)]
+    tables = [[0], [1, 2], [3, 4]]
+    outs = []
+    for runner, _ in (eager, graphed):
+        runner.kv_cache.zero_()
+        seqs = [seq(p, 0, len(p), t) for p, t in zip(prompts, tables)]
+        logits, _, need = runner.forward_logits(seqs)
+        assert need.tolist() == [0, 1, 2]
+        steps = []
+        for _ in range(4):
+            toks = logits.float().argmax(-1).tolist()
+            for s, t in zip(seqs, toks):
+                s.num_cached_tokens += s.num_new_tokens
+                s.append_token(t)
+                s.num_new_tokens = 1
+                s.block_table = tables[seqs.index(s)][:(len(s) + 255) // 256]
+            logits, _, _ = runner.forward_logits(seqs)
+            steps.append(logits.cpu())
+        outs.append(torch.stack(steps))
+    assert graphed[0].graphs and not eager[0].graphs
+    assert torch.equal(outs[0], outs[1])                 # same kernels, same order: bit-identical
+
+
+def test_run_samples_and_reports_need(eager):
+    runner, _ = eager
+    runner.kv_cache.zero_()
+    s = seq(list(range(10)), 0, 10, [6])
+    s.temperature = 1e-9
+    toks, need = runner.run([s])
+    assert need.tolist() == [0] and len(toks) == 1 and 0 <= toks[0] < 1024
+    logits, _, _ = runner.forward_logits([s])
+    assert toks[0] == int(logits.float().argmax(-1)[0])  # near-zero temperature == greedy
