@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Benchmark of the nano-vllm operator path on MI355X (gfx950).
+
+Metric (BASELINE.json): decode tok/s + prefill tok/s, Qwen3-0.6B, bf16, tensor parallel over
+the launched ranks; % of the HBM roofline (decode) and of the bf16 MFMA peak (prefill).
+
+A "step" is one pass of the hot path - ModelRunner.run(): batch flattening, one H2D copy,
+the forward (hipGraph replay for decode), LM head, sampler, token ids back on the host - over
+B sequences that each decode one token at ~1024 tokens of context (synthetic token ids,
+random-init weights of the Qwen3-0.6B architecture).  `value` = B * steps / wall time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--context C]
+  N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Extra keys: `roofline` (dominant kernel, HIP-event timed),
+`step_roofline` (all algorithmic bytes of a step / step time), `prefill` (1024-token chunks),
+`decode_sweep` (other batch sizes), `cpu_baseline` (the CPU oracle on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT / "nano-vllm-v1_amd"))
+sys.path.insert(0, str(ROOT))
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 spec peak
+MODEL_DIR = ROOT / "nano-vllm-v1_amd" / "model_configs" / "qwen3-0.6b"
+PAGE = 256
+
+
+def algorithmic_bytes_per_decode_step(hf, contexts, tp=1):
+    """Weights (every matrix once, LM head included) + KV rows of every context token, bf16."""
+    d = hf.head_dim
+    p_layer = hf.hidden_size * (hf.num_attention_heads + 2 * hf.num_key_value_heads) * d \
+        + hf.num_attention_heads * d * hf.hidden_size + 3 * hf.hidden_size * hf.intermediate_size
+    weights = 2 * (hf.num_hidden_layers * p_layer + hf.vocab_size * hf.hidden_size) // tp
+    kv_per_token = 2 * hf.num_hidden_layers * hf.num_key_value_heads * d * 2 // tp
+    return weights + kv_per_token * int(sum(contexts)), weights, kv_per_token
+
+
+def algorithmic_flops_per_chunk(hf, t, cached, tp=1):
+    d = hf.head_dim
+    p_layer = hf.hidden_size * (hf.num_attention_heads + 2 * hf.num_key_value_heads) * d \
+        + hf.num_attention_heads * d * hf.hidden_size + 3 * hf.hidden_size * hf.intermediate_size
+    linear = t * 2 * hf.num_hidden_layers * p_layer
+    visible = t * cached + t * (t + 1) // 2
+    attn = 4 * hf.num_hidden_layers * hf.num_attention_heads * d * visible
+    return (linear + attn) / tp
+
+
+class Driver:
+    """Minimal stand-in for the scheduler: sequential page allocation, one list of live sequences."""
+
+    def __init__(self, runner):
+        from nanovllm.engine.sequence import Sequence
+        self.Sequence = Sequence
+        self.runner = runner
+        self.next_page = 0
+        self.num_pages = runner.config.num_kvcache_blocks
+
+    def reset(self):
+        self.next_page = 0
+
+    def new_seq(self, tokens, temperature=0.6):
+        from nanovllm.sampling_params import SamplingParams
+        return self.Sequence(tokens, SamplingParams(temperature=temperature, max_tokens=1 << 30, ignore_eos=True))
+
+    def grow(self, s, ctx):
+        while len(s.block_table) * PAGE < ctx:
+            assert self.next_page < self.num_pages, "KV pool exhausted"
+            s.block_table.append(self.next_page)
+            self.next_page += 1
+
+    def prefill(self, seqs, chunk):
+        """Chunked prefill, one sequence at a time, `chunk` tokens per step; returns seconds per chunk list."""
+        times = []
+        for s in seqs:
+            prompt_len = len(s)
+            while s.num_cached_tokens < prompt_len:
+                n = min(chunk, prompt_len - s.num_cached_tokens)
+                s.num_new_tokens = n
+                self.grow(s, s.num_cached_tokens + n)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                toks, need = self.runner.run([s])
+                torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0, n, s.num_cached_tokens))
+                s.num_cached_tokens += n
+                s.num_new_tokens = 0
+                if toks:
+                    s.append_token(toks[0])
+        return times
+
+    def decode_step(self, seqs):
+        for s in seqs:
+            s.num_new_tokens = 1
+            self.grow(s, s.num_cached_tokens + 1)
+        toks, need = self.runner.run(seqs)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            # only rank 0 samples; every rank must feed the same ids to the next step
+            t = torch.tensor(toks if toks is not None else [0] * len(seqs), dtype=torch.int64, device="cuda")
+            dist.broadcast(t, 0)
+            toks = t.tolist()
+        for s, t in zip(seqs, toks):
+            s.num_cached_tokens += 1
+            s.num_new_tokens = 0
+            s.append_token(int(t))
+
+
+def sync_all(distributed):
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def time_decode(driver, seqs, steps, warmup, distributed):
+    for _ in range(warmup):
+        driver.decode_step(seqs)
+    sync_all(distributed)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        driver.decode_step(seqs)
+    sync_all(distributed)
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_roofline(runner, seqs, iters):
+    """Average duration of the dominant decode kernel (paged attention over the KV pool), timed with
+    HIP events on the launch stream; every launch reads a different layer's cache, as a real step does."""
+    from nanovllm import ops
+    from nanovllm.engine.model_runner import flatten_batch
+    hf = runner.config.hf_config
+    tp = runner.world_size
+    fb = flatten_batch(seqs)
+    ctx = torch.from_numpy(fb["context_lens"]).cuda()
+    tables = torch.from_numpy(fb["block_tables"]).cuda()
+    b = len(seqs)
+    hq, hkv, d = hf.num_attention_heads // tp, hf.num_key_value_heads // tp, hf.head_dim
+    q = torch.randn(b, hq, d, device="cuda").to(torch.bfloat16)
+    splits = ops.suggest_decode_splits(b, hkv, runner.config.max_model_len)
+    layers = hf.num_hidden_layers
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(layers)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(layers)]
+    total_ms, n = 0.0, 0
+    for it in range(iters + 1):
+        for li in range(layers):
+            starts[li].record()
+            ops.attn_decode(q, runner.kv_cache[0, li], runner.kv_cache[1, li], ctx, tables, d ** -0.5, num_splits=splits)
+            ends[li].record()
+        torch.cuda.synchronize()
+        if it:                              # first sweep is warm-up
+            total_ms += sum(s.elapsed_time(e) for s, e in zip(starts, ends))
+            n += layers
+    avg_ms = total_ms / n
+    bytes_per_launch = int(fb["context_lens"].sum()) * hkv * d * 2 * 2      # K and V rows, bf16
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="attn_decode_kernel" + ("+combine" if splits > 1 else ""), achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                avg_launch_us=round(avg_ms * 1e3, 2), bytes_per_launch=bytes_per_launch, launches_timed=n)
+
+
+def cpu_baseline(hf, budget_s=12.0):
+    """The CPU oracle (oracle/ref_model.py, torch-CPU eager) on the same architecture and weight
+    recipe, timed on this host: decode, B=8 sequences at context 128."""
+    from oracle import ref_model as M
+    torch.manual_seed(0)
+    shape = M.ModelShape(hidden_size=hf.hidden_size, num_hidden_layers=hf.num_hidden_layers,
+                         num_attention_heads=hf.num_attention_heads, num_key_value_heads=hf.num_key_value_heads,
+                         head_dim=hf.head_dim, intermediate_size=hf.intermediate_size, vocab_size=hf.vocab_size,
+                         max_position_embeddings=4096, tie_word_embeddings=True)
+    w = M.random_weights(shape, seed=0)
+    b, ctx = 8, 128
+    runner = M.RefRunner(shape, w, num_blocks=b)
+    g = torch.Generator().manual_seed(0)
+    seqs = [M.SeqState(torch.randint(0, 10000, (ctx,), generator=g).tolist(), 0, ctx, [i]) for i in range(b)]
+    t0 = time.perf_counter()
+    logits, _ = runner.run(seqs)                               # prefill (also timed: prefill tok/s)
+    prefill_s = time.perf_counter() - t0
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        toks = logits.float().argmax(-1).tolist()
+        for s, t in zip(seqs, toks):
+            s.num_cached_tokens += s.num_new_tokens
+            s.token_ids.append(t)
+            s.num_new_tokens = 1
+        logits, _ = runner.run(seqs)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s and steps >= 2:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(b * steps / dt, 2), unit="tok/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"Qwen3-0.6B shape, decode B={b} ctx={ctx}, {steps} steps in {dt:.1f}s (oracle/ref_model.py, torch-CPU eager bf16); "
+                       f"prefill {b}x{ctx} tokens in {prefill_s:.1f}s = {b * ctx / prefill_s:.0f} tok/s",
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--context", type=int, default=1024)
+    ap.add_argument("--no-extras", action="store_true", help="skip sweeps, long prefill and the CPU baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+
+    b, ctx0 = args.batch, args.context
+    total_steps = args.steps + args.warmup
+    max_len = 8192 + 64
+    pages_decode = b * ((ctx0 + total_steps + 64 + PAGE) // PAGE + 1)
+    pages = max(pages_decode, 8 * (max_len // PAGE + 1)) + 16
+    cfg = Config(str(MODEL_DIR), max_num_batched_tokens=1024, max_num_seqs=max(b, 8), max_model_len=max_len,
+                 tensor_parallel_size=world, enforce_eager=False, chunked_prefill=True, num_kvcache_blocks=pages)
+    hf = cfg.hf_config
+    t_init = time.perf_counter()
+    runner = ModelRunner(cfg, rank, [])
+    init_s = time.perf_counter() - t_init
+    driver = Driver(runner)
+    g = torch.Generator().manual_seed(0)
+
+    def prompts(n, length):
+        return [torch.randint(0, 10000, (length,), generator=g).tolist() for _ in range(n)]
+
+    # ---- prefill of the decode batch: B prompts x context tokens, one 1024-token chunk per step
+    seqs = [driver.new_seq(p) for p in prompts(b, ctx0)]
+    ptimes = driver.prefill(seqs, 1024)
+    steady = [x for x in ptimes[len(ptimes) // 4:]] or ptimes
+    chunk_s = sum(x[0] for x in steady) / len(steady)
+    chunk_tokens = sum(x[1] for x in steady) / len(steady)
+    chunk_flops = sum(algorithmic_flops_per_chunk(hf, x[1], x[2], world) for x in steady) / len(steady)
+    prefill = dict(tok_s=round(chunk_tokens / chunk_s, 1), ms_per_chunk=round(chunk_s * 1e3, 3),
+                   chunk_tokens=int(chunk_tokens), chunks_timed=len(steady),
+                   roofline=dict(bound="mfma", achieved=round(chunk_flops / chunk_s / 1e12, 2), peak=MFMA_PEAK_TFLOPS,
+                                 unit="TFLOP/s", frac=round(chunk_flops / chunk_s / 1e12 / MFMA_PEAK_TFLOPS, 4)),
+                   note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included")
+
+    # ---- the timed region: K decode steps of B sequences
+    dt = time_decode(driver, seqs, args.steps, args.warmup, distributed)
+    value = b * args.steps / dt
+    contexts = [s.num_cached_tokens - args.steps / 2 for s in seqs]          # mean context over the timed steps
+    step_bytes, w_bytes, kv_tok = algorithmic_bytes_per_decode_step(hf, contexts, world)
+    step_gbs = step_bytes / (dt / args.steps) / 1e9
+    out = dict(metric="decode tok/s (Qwen3-0.6B, bf16; prefill tok/s and roofline fractions in `prefill`/`roofline`)",
+               value=round(value, 1), unit="tok/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="strong", vs_baseline=None,
+               dtype="bf16", data="synthetic token ids, random-init weights (Qwen3-0.6B architecture)",
+               config=dict(workload=f"Qwen3-0.6B TP={world} bf16 decode, B={b} sequences x ~{ctx0} context tokens, "
+                                    "chunked_prefill on, max_num_batched_tokens=1024, hipGraph decode",
+                           batch=b, context=ctx0, parallelism=f"tp{world}", kv_page=PAGE),
+               step_roofline=dict(bound="hbm", achieved=round(step_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=round(step_gbs / HBM_PEAK_GBS, 4), bytes_per_step=int(step_bytes),
+                                  weight_bytes=int(w_bytes), kv_bytes_per_context_token=int(kv_tok)),
+               prefill=prefill, init_s=round(init_s, 1))
+    out["roofline"] = kernel_roofline(runner, seqs, iters=4)
+
+    if not args.no_extras:
+        # ---- decode at other batch sizes (same sequences, subsets)
+        sweep = {}
+        for bb in (1, 8, 32, 128):
+            if bb >= b:
+                continue
+            sub = seqs[:bb]
+            k = 32
+            d2 = time_decode(driver, sub, k, 4, distributed)
+            sb, _, _ = algorithmic_bytes_per_decode_step(hf, [s.num_cached_tokens - k / 2 for s in sub], world)
+            sweep[f"B{bb}"] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
+                                   hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
+        out["decode_sweep"] = sweep
+        # ---- long-context chunked prefill: 8192-token prompts, 8 chunks of 1024 each
+        driver_pages = driver.next_page
+        long_seqs = [driver.new_seq(p) for p in prompts(2, 8192)]
+        lt = driver.prefill(long_seqs, 1024)[8:]                                 # second prompt (first warms up)
+        tot_s = sum(x[0] for x in lt)
+        tot_f = sum(algorithmic_flops_per_chunk(hf, x[1], x[2], world) for x in lt)
+        out["prefill_8k"] = dict(tok_s=round(sum(x[1] for x in lt) / tot_s, 1), tflops=round(tot_f / tot_s / 1e12, 2),
+                                 mfma_frac=round(tot_f / tot_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                 ms_per_chunk=[round(x[0] * 1e3, 3) for x in lt])
+        if rank == 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(hf)
+    if rank == 0:
+        print(json.dumps(out))
+    runner.exit()
+    if distributed and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -289,7 +289,8 @@ class ModelRunner:
         """The captured graph that fits this step, or None (eager)."""
         bs = len(fb["context_lens"])
         if (self.enforce_eager or not self.graphs or fb["block_tables"] is None or fb["max_seqlen_q"] != 1
-                or fb["input_ids"].size != bs or bs > self.graph_bs[-1]):
+                or fb["input_ids"].size != bs or bs > self.graph_bs[-1]
+                or fb["block_tables"].shape[1] > self.graph_width):
             return None
         return self.graphs[next(x for x in self.graph_bs if x >= bs)]
 
@@ -326,7 +327,7 @@ class ModelRunner:
     def capture_graphs(self):
         cfg = self.config
         max_bs = min(cfg.max_num_seqs, 512)
-        width = (cfg.max_model_len + self.block_size - 1) // self.block_size
+        width = self.graph_width = (cfg.max_model_len + self.block_size - 1) // self.block_size
         self.graph_bs = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
         pool = None
         for bs in reversed(self.graph_bs):
