@@ -162,6 +162,63 @@ int32_t nvh_sample_with_noise(const void* logits, int32_t logits_is_f32, int64_t
 int32_t nvh_argmax(const void* logits, int32_t logits_is_f32, int64_t row_stride, int64_t* out,
                    int64_t rows, int64_t vocab, nvh_stream_t stream);
 
+/* ---- whole-model executor: the layer loop of models/qwen3.py:401-441 (Qwen3Model.forward) and
+ * compute_logits (:509-533), issued from native code so one call enqueues every kernel of a step
+ * (single rank; tensor-parallel runs use the operator modules + RCCL between them).
+ * Same kernels, same order and same rounding points as calling the entry points above one by one:
+ *   embedding -> L x { (add+)RMSNorm -> QKV GEMM -> q/k norm + RoPE + KV store -> attention ->
+ *   O GEMM (split-K slabs) -> add+RMSNorm (sums slabs) -> gate/up GEMM -> SiLU*mul -> down GEMM } ->
+ *   add+RMSNorm.
+ * All pointer arrays have `layers` entries and live in HOST memory; they are read during the call only. */
+typedef struct {
+    int32_t hidden, layers, num_q_heads, num_kv_heads, head_dim, inter;
+    int32_t vocab_rows, reserved;
+    float eps;
+    int32_t reserved2;
+    int64_t max_position;
+    const void* embed;                 /* [vocab_rows, hidden] */
+    const void* final_norm;            /* [hidden] */
+    const void* lm_head;               /* [vocab_rows, hidden] */
+    const float* cos_sin;              /* fp32 [max_position, head_dim] */
+    const void* const* qkv_w;          /* [(Hq+2Hkv)*D, hidden] */
+    const void* const* o_w;            /* [hidden, Hq*D] */
+    const void* const* q_norm;         /* [D] */
+    const void* const* k_norm;         /* [D] */
+    const void* const* gate_up_w;      /* [2*inter, hidden] */
+    const void* const* down_w;         /* [hidden, inter] */
+    const void* const* input_norm;     /* [hidden] */
+    const void* const* post_norm;      /* [hidden] */
+    void* const* k_cache;              /* [pages,256,Hkv,D] per layer, or NULL array entries before the pool exists */
+    void* const* v_cache;
+} nvh_qwen3_model;
+
+#define NVH_MODE_PACKED 0   /* layers/attention.py: block_tables is None (K/V = new tokens) */
+#define NVH_MODE_PAGED 1    /* var-len queries over the paged cache */
+#define NVH_MODE_DECODE 2   /* one query per sequence (graph decode / eager decode) */
+
+typedef struct {
+    int64_t num_tokens, batch;
+    const int64_t* input_ids;          /* [T] */
+    const int64_t* positions;          /* [T] */
+    const int32_t* cu_seqlens_q;       /* [B+1] (unused in NVH_MODE_DECODE) */
+    const int32_t* cu_seqlens_k;       /* [B+1] (unused in NVH_MODE_DECODE) */
+    const int32_t* slot_mapping;       /* [T] or NULL (no KV store) */
+    const int32_t* context_lens;       /* [B] (NVH_MODE_DECODE) */
+    const int32_t* block_tables;       /* [B, table_stride] or NULL */
+    int64_t table_stride;
+    int32_t max_seqlen_q, max_seqlen_k;
+    int32_t mode, decode_splits;       /* decode_splits >= 1 */
+} nvh_step;
+
+int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_tokens, int64_t batch, int32_t decode_splits);
+/* hidden_out: bf16 [T, hidden] (the final-norm output). */
+int32_t nvh_qwen3_forward(const nvh_qwen3_model* model, const nvh_step* step, void* hidden_out,
+                          void* workspace, int64_t workspace_bytes, nvh_stream_t stream);
+/* logits [num_rows, vocab_rows] bf16 = lm_head(hidden[last rows]); layers/embed_head.py:197-204.
+ * rows_ws: bf16 [num_rows, hidden] scratch; cu_seqlens_q NULL -> hidden rows are used as they are. */
+int32_t nvh_qwen3_logits(const nvh_qwen3_model* model, const void* hidden, const int32_t* cu_seqlens_q,
+                         const int32_t* need, int64_t num_rows, void* rows_ws, void* logits, nvh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

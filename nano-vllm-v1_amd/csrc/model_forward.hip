@@ -1,0 +1,142 @@
+// Native step executor: enqueues every kernel of a Qwen3 forward pass from one call, so the host
+// cost of a step is ~250 HIP launches instead of ~250 Python -> ctypes round trips.  It calls the
+// same entry points a caller would call one by one (identical kernels, order and rounding).
+#include "common.h"
+
+namespace {
+struct Workspace {
+    bf16 *residual, *x, *y, *qkv, *attn, *gate_up, *act;
+    float* slabs;
+    void* decode_ws;
+    int64_t total;
+};
+
+inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
+
+int32_t split_for(int64_t m, int64_t n, int64_t k) { return nvh_gemm_suggest_split_k(m, n, k); }
+
+Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_splits, char* base) {
+    const int64_t h = md->hidden, d = md->head_dim;
+    const int64_t qsz = (int64_t)md->num_q_heads * d, kvsz = (int64_t)md->num_kv_heads * d;
+    Workspace w;
+    int64_t off = 0;
+    auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    w.residual = (bf16*)take(t * h * 2);
+    w.x = (bf16*)take(t * h * 2);
+    w.y = (bf16*)take(t * h * 2);
+    w.qkv = (bf16*)take(t * (qsz + 2 * kvsz) * 2);
+    w.attn = (bf16*)take(t * qsz * 2);
+    w.gate_up = (bf16*)take(t * 2 * md->inter * 2);
+    w.act = (bf16*)take(t * md->inter * 2);
+    const int64_t so = split_for(t, h, qsz), sd = split_for(t, h, md->inter);
+    const int64_t smax = so > sd ? so : sd;
+    w.slabs = (float*)take(smax > 1 ? smax * t * h * 4 : 0);
+    w.decode_ws = take(nvh_attn_decode_workspace_bytes(b, md->num_q_heads, d, decode_splits));
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_tokens, int64_t batch,
+                                             int32_t decode_splits) {
+    if (!model || num_tokens < 0) return -1;
+    return carve(model, num_tokens, batch, decode_splits < 1 ? 1 : decode_splits, nullptr).total;
+}
+
+#define FWD(call)                 \
+    do {                          \
+        int32_t rc__ = (call);    \
+        if (rc__ != NVH_OK) return rc__; \
+    } while (0)
+
+extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* st, void* hidden_out, void* workspace,
+                                     int64_t workspace_bytes, nvh_stream_t stream) {
+    NVH_REQUIRE(md && st && hidden_out, NVH_EINVAL, "nvh_qwen3_forward: null pointer");
+    NVH_REQUIRE(md->head_dim == 128, NVH_ENOSYS, "nvh_qwen3_forward: head_dim %d unsupported", md->head_dim);
+    const int64_t t = st->num_tokens, b = st->batch;
+    if (t == 0) return NVH_OK;
+    const int32_t dsplits = st->decode_splits < 1 ? 1 : st->decode_splits;
+    NVH_REQUIRE(workspace && nvh_aligned16(workspace), NVH_EINVAL, "nvh_qwen3_forward: workspace missing or misaligned");
+    Workspace w = carve(md, t, b, dsplits, (char*)workspace);
+    NVH_REQUIRE(w.total <= workspace_bytes, NVH_EINVAL, "nvh_qwen3_forward: workspace too small (%ld < %ld)",
+                (long)workspace_bytes, (long)w.total);
+    NVH_REQUIRE(st->mode == NVH_MODE_PACKED || st->block_tables, NVH_EINVAL, "nvh_qwen3_forward: paged modes need block_tables");
+    NVH_REQUIRE(st->mode != NVH_MODE_DECODE || (st->context_lens && t == b), NVH_EINVAL, "nvh_qwen3_forward: decode mode needs context_lens and one token per sequence");
+
+    const int64_t h = md->hidden, d = md->head_dim, hq = md->num_q_heads, hkv = md->num_kv_heads;
+    const int64_t qsz = hq * d, kvsz = hkv * d, qkv_n = qsz + 2 * kvsz;
+    const float scale = 1.0f / sqrtf((float)d);
+    const int32_t so = split_for(t, h, qsz), sd = split_for(t, h, md->inter);
+
+    FWD(nvh_embedding(st->input_ids, md->embed, w.residual, t, h, 0, md->vocab_rows, stream));
+    bool pending_slabs = false;         // the previous projection left split-K slabs in w.slabs
+    int32_t pending_count = 0;
+    bf16* pending_y = nullptr;          // or a reduced bf16 result
+    for (int l = 0; l < md->layers; ++l) {
+        // ---- input norm: layer 0 normalises the embedding; later layers add the MLP output first
+        if (l == 0) {
+            FWD(nvh_rmsnorm(w.residual, h, md->input_norm[l], w.x, h, t, h, md->eps, stream));
+        } else {
+            FWD(nvh_add_rmsnorm(pending_y, w.residual, md->input_norm[l], w.x, t, h, md->eps,
+                                pending_slabs ? w.slabs : nullptr, pending_count, stream));
+        }
+        // ---- attention block
+        FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, w.qkv, qkv_n, t, qkv_n, h, 1, nullptr, stream));
+        void* kc = md->k_cache ? md->k_cache[l] : nullptr;
+        void* vc = md->v_cache ? md->v_cache[l] : nullptr;
+        const bool store = kc && vc && st->slot_mapping;
+        FWD(nvh_qknorm_rope_store(w.qkv, qkv_n, hq, hkv, md->q_norm[l], md->k_norm[l], md->eps, st->positions,
+                                  md->cos_sin, md->max_position, store ? kc : nullptr, store ? vc : nullptr,
+                                  store ? st->slot_mapping : nullptr, t, stream));
+        if (st->mode == NVH_MODE_DECODE) {
+            FWD(nvh_attn_decode(w.qkv, qkv_n, kc, vc, st->context_lens, st->block_tables, st->table_stride, b, hq, hkv,
+                                d, scale, w.attn, dsplits, w.decode_ws, stream));
+        } else if (st->mode == NVH_MODE_PAGED) {
+            FWD(nvh_attn_varlen(w.qkv, qkv_n, kc, vc, kvsz, st->cu_seqlens_q, st->cu_seqlens_k, st->block_tables,
+                                st->table_stride, b, st->max_seqlen_q, t, hq, hkv, d, scale, w.attn, stream));
+        } else {
+            FWD(nvh_attn_varlen(w.qkv, qkv_n, w.qkv + qsz, w.qkv + qsz + kvsz, qkv_n, st->cu_seqlens_q, st->cu_seqlens_k,
+                                nullptr, 0, b, st->max_seqlen_q, t, hq, hkv, d, scale, w.attn, stream));
+        }
+        // ---- O projection -> add + norm
+        if (so > 1) {
+            FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, nullptr, h, t, h, qsz, so, w.slabs, stream));
+            FWD(nvh_add_rmsnorm(nullptr, w.residual, md->post_norm[l], w.x, t, h, md->eps, w.slabs, so, stream));
+        } else {
+            FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, w.y, h, t, h, qsz, 1, nullptr, stream));
+            FWD(nvh_add_rmsnorm(w.y, w.residual, md->post_norm[l], w.x, t, h, md->eps, nullptr, 0, stream));
+        }
+        // ---- MLP
+        FWD(nvh_gemm_bf16_nt(w.x, h, md->gate_up_w[l], nullptr, w.gate_up, 2 * md->inter, t, 2 * md->inter, h, 1, nullptr, stream));
+        FWD(nvh_silu_mul(w.gate_up, w.act, t, md->inter, stream));
+        if (sd > 1) {
+            FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, nullptr, h, t, h, md->inter, sd, w.slabs, stream));
+            pending_slabs = true;
+            pending_count = sd;
+            pending_y = nullptr;
+        } else {
+            FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, w.y, h, t, h, md->inter, 1, nullptr, stream));
+            pending_slabs = false;
+            pending_count = 0;
+            pending_y = w.y;
+        }
+    }
+    FWD(nvh_add_rmsnorm(pending_y, w.residual, md->final_norm, hidden_out, t, h, md->eps,
+                        pending_slabs ? w.slabs : nullptr, pending_count, stream));
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_qwen3_logits(const nvh_qwen3_model* md, const void* hidden, const int32_t* cu_seqlens_q,
+                                    const int32_t* need, int64_t num_rows, void* rows_ws, void* logits,
+                                    nvh_stream_t stream) {
+    NVH_REQUIRE(md && hidden && logits, NVH_EINVAL, "nvh_qwen3_logits: null pointer");
+    if (num_rows == 0) return NVH_OK;
+    const void* rows = hidden;
+    if (cu_seqlens_q) {
+        NVH_REQUIRE(rows_ws, NVH_EINVAL, "nvh_qwen3_logits: rows_ws missing");
+        FWD(nvh_gather_last_rows(hidden, cu_seqlens_q, need, rows_ws, num_rows, md->hidden, stream));
+        rows = rows_ws;
+    }
+    return nvh_gemm_bf16_nt(rows, md->hidden, md->lm_head, nullptr, logits, md->vocab_rows, num_rows, md->vocab_rows,
+                            md->hidden, 1, nullptr, stream);
+}

@@ -29,6 +29,8 @@ from .. import _hip
 from ..config import Config, model_dtype
 from ..layers.sampler import Sampler
 from ..models.qwen3 import Qwen3ForCausalLM
+from ..native import MODE_DECODE, MODE_PACKED, MODE_PAGED, NativeQwen3
+from .. import ops
 from ..utils.context import get_context, reset_context, set_context
 from ..utils.loader import has_checkpoint, load_model, load_tensors, synthetic_tensors
 from .sequence import Sequence
@@ -155,8 +157,15 @@ class ModelRunner:
             self.sampler = Sampler()
             self.staging = _Staging(self.device)
             self.graphs, self.graph_bs = {}, []
+            # one native call per step on a single rank; the operator modules (with RCCL between
+            # them) otherwise.  NANOVLLM_NATIVE=0 forces the module path (parity tests use it).
+            use_native = self.world_size == 1 and os.environ.get("NANOVLLM_NATIVE", "1") != "0" \
+                and not getattr(hf, "attention_bias", True)
+            self.native = NativeQwen3(self.model) if use_native else None
             self.warmup_model()
             self.allocate_kv_cache()
+            if self.native is not None:
+                self.native.rebuild()
             if not self.enforce_eager:
                 self.capture_graphs()
         finally:
@@ -285,6 +294,24 @@ class ModelRunner:
     def run_model(self, input_ids: torch.Tensor, positions: torch.Tensor):
         return self.model.compute_logits(self.model(input_ids, positions))
 
+    def forward_hidden(self, input_ids, positions, fb):
+        """Final-norm hidden states [T, H] for the step whose Context is set."""
+        if self.native is None:
+            return self.model(input_ids, positions)
+        ctx = get_context()
+        bs = len(fb["context_lens"])
+        if ctx.block_tables is None:
+            mode, splits = MODE_PACKED, 1
+        elif fb["max_seqlen_q"] == 1:
+            mode = MODE_DECODE
+            splits = ops.suggest_decode_splits(bs, self.model.model.layers[0].self_attn.num_kv_heads, fb["max_seqlen_k"])
+        else:
+            mode, splits = MODE_PAGED, 1
+        return self.native.forward(input_ids, positions, mode=mode, batch=bs, cu_seqlens_q=ctx.cu_seqlens_q,
+                                   cu_seqlens_k=ctx.cu_seqlens_k, max_seqlen_q=fb["max_seqlen_q"],
+                                   max_seqlen_k=fb["max_seqlen_k"], slot_mapping=ctx.slot_mapping,
+                                   context_lens=ctx.context_lens, block_tables=ctx.block_tables, decode_splits=splits)
+
     def _graph_for(self, fb):
         """The captured graph that fits this step, or None (eager)."""
         bs = len(fb["context_lens"])
@@ -306,11 +333,19 @@ class ModelRunner:
         skip_logits = fb["need"].size == 0 and has_tables
         if graph is not None:
             hidden, temps = graph.replay(fb, seqs, self.rank == 0)
-            logits = self.model.lm_head.forward_rows(hidden[:len(seqs)])
+            rows = hidden[:len(seqs)]
+            logits = self.native.logits(rows) if self.native is not None else self.model.lm_head.forward_rows(rows)
         else:
             input_ids, positions, temps, _ = self.prepare_model_input(seqs, fb)
-            hidden = self.model(input_ids, positions)
-            logits = None if skip_logits else self.model.compute_logits(hidden)
+            hidden = self.forward_hidden(input_ids, positions, fb)
+            if skip_logits:
+                logits = None
+            elif self.native is not None:
+                ctx = get_context()
+                n = fb["need"].size or len(seqs)
+                logits = self.native.logits(hidden, ctx.cu_seqlens_q, ctx.seq_need_compute_logits if fb["need"].size else None, n)
+            else:
+                logits = self.model.compute_logits(hidden)
         reset_context()
         return logits, temps, need_host
 
@@ -359,13 +394,23 @@ class _DecodeGraph:
         self.d = dv
         self.h["slot_mapping"][:] = -1
         self.dev.copy_(self.host)
-        model = runner.model
         set_context(slot_mapping=dv["slot_mapping"], context_lens=dv["context_lens"], block_tables=dv["block_tables"])
-        model(dv["input_ids"], dv["positions"])                       # warm-up (allocator, lazy module state)
+        if runner.native is not None:
+            hkv = runner.model.model.layers[0].self_attn.num_kv_heads
+            splits = ops.suggest_decode_splits(bs, hkv, runner.config.max_model_len)
+
+            def fwd():
+                return runner.native.forward(dv["input_ids"], dv["positions"], mode=MODE_DECODE, batch=bs,
+                                             slot_mapping=dv["slot_mapping"], context_lens=dv["context_lens"],
+                                             block_tables=dv["block_tables"], decode_splits=splits)
+        else:
+            def fwd():
+                return runner.model(dv["input_ids"], dv["positions"])
+        fwd()                                                         # warm-up (allocator, lazy state)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, pool):
-            self.out = model(dv["input_ids"], dv["positions"])
+            self.out = fwd()
         self.pool = self.graph.pool()
         reset_context()
 

@@ -1,0 +1,110 @@
+"""Binding of the native step executor (nvh_qwen3_forward / nvh_qwen3_logits): builds the
+`nvh_qwen3_model` descriptor from a Qwen3ForCausalLM module once, and runs one step per call.
+
+The descriptor holds raw device pointers into the module's parameters and KV-cache views; the
+module keeps owning them.  Single rank only (tensor-parallel runs go through the operator modules,
+which all-reduce between kernels)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _hip
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+PP = C.POINTER(vp)
+
+MODE_PACKED, MODE_PAGED, MODE_DECODE = 0, 1, 2
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("hidden", i32), ("layers", i32), ("num_q_heads", i32), ("num_kv_heads", i32), ("head_dim", i32),
+                ("inter", i32), ("vocab_rows", i32), ("reserved", i32), ("eps", f32), ("reserved2", i32),
+                ("max_position", i64), ("embed", vp), ("final_norm", vp), ("lm_head", vp), ("cos_sin", vp),
+                ("qkv_w", PP), ("o_w", PP), ("q_norm", PP), ("k_norm", PP), ("gate_up_w", PP), ("down_w", PP),
+                ("input_norm", PP), ("post_norm", PP), ("k_cache", PP), ("v_cache", PP)]
+
+
+class StepDesc(C.Structure):
+    _fields_ = [("num_tokens", i64), ("batch", i64), ("input_ids", vp), ("positions", vp), ("cu_seqlens_q", vp),
+                ("cu_seqlens_k", vp), ("slot_mapping", vp), ("context_lens", vp), ("block_tables", vp),
+                ("table_stride", i64), ("max_seqlen_q", i32), ("max_seqlen_k", i32), ("mode", i32), ("decode_splits", i32)]
+
+
+def _ptr(t):
+    return 0 if t is None or t.numel() == 0 else t.data_ptr()
+
+
+class NativeQwen3:
+    def __init__(self, model):
+        self.lib = _hip.lib()
+        self.model = model
+        self.rebuild()
+
+    def rebuild(self):
+        """(Re)read every pointer - call again after the KV cache views are bound."""
+        m = self.model
+        layers = list(m.model.layers)
+        a0 = layers[0].self_attn
+        assert not a0.qkv_bias, "the native executor covers the q/k-norm (bias-free) Qwen3 layout"
+        self._arrays = {}
+
+        def arr(name, tensors):
+            a = (vp * len(tensors))(*[_ptr(t) for t in tensors])
+            self._arrays[name] = a
+            return C.cast(a, PP)
+
+        d = ModelDesc()
+        d.hidden = m.model.embed_tokens.weight.shape[1]
+        d.layers = len(layers)
+        d.num_q_heads, d.num_kv_heads, d.head_dim = a0.num_heads, a0.num_kv_heads, a0.head_dim
+        d.inter = layers[0].mlp.down_proj.weight.shape[1]
+        d.vocab_rows = m.lm_head.weight.shape[0]
+        d.eps = layers[0].input_layernorm.eps
+        table = a0.rotary_emb.table2d()
+        self._keep = [table]
+        d.max_position = table.shape[0]
+        d.embed, d.final_norm = m.model.embed_tokens.weight.data_ptr(), m.model.norm.weight.data_ptr()
+        d.lm_head, d.cos_sin = m.lm_head.weight.data_ptr(), table.data_ptr()
+        d.qkv_w = arr("qkv", [l.self_attn.qkv_proj.weight for l in layers])
+        d.o_w = arr("o", [l.self_attn.o_proj.weight for l in layers])
+        d.q_norm = arr("qn", [l.self_attn.q_norm.weight for l in layers])
+        d.k_norm = arr("kn", [l.self_attn.k_norm.weight for l in layers])
+        d.gate_up_w = arr("gu", [l.mlp.gate_up_proj.weight for l in layers])
+        d.down_w = arr("dn", [l.mlp.down_proj.weight for l in layers])
+        d.input_norm = arr("in", [l.input_layernorm.weight for l in layers])
+        d.post_norm = arr("pn", [l.post_attention_layernorm.weight for l in layers])
+        d.k_cache = arr("kc", [l.self_attn.attn.k_cache for l in layers])
+        d.v_cache = arr("vc", [l.self_attn.attn.v_cache for l in layers])
+        self.desc = d
+        self.device = m.lm_head.weight.device
+
+    def forward(self, input_ids, positions, *, mode, batch, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0,
+                max_seqlen_k=0, slot_mapping=None, context_lens=None, block_tables=None, decode_splits=1):
+        t = input_ids.numel()
+        st = StepDesc()
+        st.num_tokens, st.batch = t, batch
+        st.input_ids, st.positions = input_ids.data_ptr(), positions.data_ptr()
+        st.cu_seqlens_q, st.cu_seqlens_k = _ptr(cu_seqlens_q), _ptr(cu_seqlens_k)
+        st.slot_mapping, st.context_lens = _ptr(slot_mapping), _ptr(context_lens)
+        st.block_tables = _ptr(block_tables)
+        st.table_stride = block_tables.stride(0) if block_tables is not None else 0
+        st.max_seqlen_q, st.max_seqlen_k, st.mode, st.decode_splits = max_seqlen_q, max_seqlen_k, mode, max(1, decode_splits)
+        nbytes = self.lib.nvh_qwen3_workspace_bytes(C.byref(self.desc), t, batch, st.decode_splits)
+        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        out = torch.empty(t, self.desc.hidden, dtype=torch.bfloat16, device=self.device)
+        _hip.check(self.lib.nvh_qwen3_forward(C.byref(self.desc), C.byref(st), out.data_ptr(), ws.data_ptr(), nbytes,
+                                              torch.cuda.current_stream().cuda_stream), "nvh_qwen3_forward")
+        return out
+
+    def logits(self, hidden, cu_seqlens_q=None, need=None, num_rows=None):
+        """lm_head over the last scheduled row of the selected sequences (cu_seqlens_q None: `hidden`
+        rows are used directly)."""
+        n = hidden.shape[0] if cu_seqlens_q is None else num_rows
+        out = torch.empty(n, self.desc.vocab_rows, dtype=torch.bfloat16, device=self.device)
+        rows = torch.empty(n, self.desc.hidden, dtype=torch.bfloat16, device=self.device) if cu_seqlens_q is not None else None
+        _hip.check(self.lib.nvh_qwen3_logits(C.byref(self.desc), hidden.data_ptr(), _ptr(cu_seqlens_q), _ptr(need), n,
+                                             _ptr(rows), out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "nvh_qwen3_logits")
+        return out

@@ -35,7 +35,9 @@ def hf_named(weights, shape):
             yield name, t
 
 
-def make_runner(enforce_eager, num_blocks=12, **kw):
+def make_runner(enforce_eager, num_blocks=12, native=True, **kw):
+    import os
+    os.environ["NANOVLLM_NATIVE"] = "1" if native else "0"
     from nanovllm.config import Config
     from nanovllm.engine.model_runner import ModelRunner
     from nanovllm.utils.loader import load_tensors
@@ -46,12 +48,21 @@ def make_runner(enforce_eager, num_blocks=12, **kw):
     weights = M.random_weights(shape, seed=0, std=0.05)
     n = load_tensors(runner.model, hf_named(weights, shape))
     assert n == 1 + 2 * 11 + 1
+    assert (runner.native is not None) == native
     return runner, M.RefRunner(shape, weights, num_blocks)
 
 
 @pytest.fixture(scope="module")
 def eager():
     r = make_runner(True)
+    yield r
+    r[0].exit()
+
+
+@pytest.fixture(scope="module")
+def modules():
+    """The operator-module path (what tensor-parallel runs use), eager."""
+    r = make_runner(True, native=False)
     yield r
     r[0].exit()
 
@@ -89,7 +100,7 @@ def test_mode_w_ragged_batch_matches_reference(eager, f2):
     assert torch.equal(logits.float().argmax(-1).cpu(), f2.bf("w_logits").float().argmax(-1))
 
 
-@pytest.mark.parametrize("which", ["eager", "graphed"])
+@pytest.mark.parametrize("which", ["eager", "graphed", "modules"])
 def test_chunked_paged_greedy_ids_bit_exact(which, request, f2):
     runner, oracle = request.getfixturevalue(which)
     runner.kv_cache.zero_()
@@ -177,3 +188,32 @@ def test_run_samples_and_reports_need(eager):
     assert need.tolist() == [0] and len(toks) == 1 and 0 <= toks[0] < 1024
     logits, _, _ = runner.forward_logits([s])
     assert toks[0] == int(logits.float().argmax(-1)[0])  # near-zero temperature == greedy
+
+
+def test_native_executor_equals_operator_modules(eager, modules):
+    """One native call per step vs the nn.Module path: same kernels in the same order -> identical bits,
+    for a packed prefill, a paged mixed batch and eager decode."""
+    g = torch.Generator().manual_seed(21)
+    p1, p2 = (torch.randint(0, 1024, (n,), generator=g).tolist() for n in (300, 40))
+    outs = []
+    for runner, _ in (eager, modules):
+        runner.kv_cache.zero_()
+        got = []
+        a = seq(p1, 0, 300, [1, 2])
+        l, _, _ = runner.forward_logits([a])                       # packed (no cached keys)
+        got.append(l.cpu())
+        a.num_cached_tokens, a.num_new_tokens = 300, 1
+        a.append_token(int(l.float().argmax(-1)[0]))
+        b = seq(p2, 0, 40, [3])
+        l, _, need = runner.forward_logits([a, b])                 # paged mixed: decode row + prefill
+        assert need.tolist() == [0, 1]
+        got.append(l.cpu())
+        a.num_cached_tokens, b.num_cached_tokens = 301, 40
+        for s_, t_ in zip((a, b), l.float().argmax(-1).tolist()):
+            s_.append_token(t_)
+            s_.num_new_tokens = 1
+        l, _, _ = runner.forward_logits([a, b])                    # eager decode
+        got.append(l.cpu())
+        outs.append(got)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
