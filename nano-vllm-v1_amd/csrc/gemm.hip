@@ -3,8 +3,12 @@
 // fragment shape (8 consecutive k per lane), so tiles go global -> LDS by 16-byte LDS-DMA
 // (global_load_lds) with no register staging and no transposes.
 //
-// Workgroup = 4 waves, tile BM(x rows) x BN(W rows) x 64(k), double-buffered LDS, one
-// barrier per k-tile: the DMA of tile t+1 is in flight while tile t is multiplied.
+// Workgroup = 4 waves, tile BM(x rows) x BN(W rows) x 64(k), a ring of STAGES LDS buffers and
+// ONE barrier per k-tile.  The DMA of tile t+STAGES-1 is issued while tile t is multiplied and
+// stays in flight across the barriers: each wave waits with a COUNTED s_waitcnt vmcnt(n) for its
+// own pieces of tile t only, then a raw s_barrier makes every wave's pieces visible.  That keeps
+// STAGES-1 tiles of HBM/L2 latency covered per workgroup, which is what small-M (decode) and
+// short-K shapes need: they are bound by the dependent load chain, not by MFMA or bandwidth.
 // W rows are the MFMA "A" operand and x rows the "B" operand, so each lane ends up with 4
 // consecutive output columns (n) of one output row (m) -> 8-byte bf16 / 16-byte fp32 stores.
 //
@@ -13,59 +17,78 @@
 // read touches all 64 banks exactly once.  LDS-DMA writes lane-linear, so the XOR is applied
 // to the per-lane SOURCE address and again on the read.
 //
-// Small M (decode) uses BM = 16/32/64 so the grid is set by N; split-K (gridDim.z) spreads
-// narrow-N projections over the chip, writing fp32 slabs that the consumer kernel sums.
+// The tile shape is picked per call so that the grid covers the 256 CUs (small tiles for narrow
+// outputs, BM = 16/32/64 for decode batches); split-K (gridDim.z) adds workgroups for narrow-N
+// projections, writing fp32 slabs that the consumer kernel sums.
 #include "common.h"
 
 #define BK 64
 
-template <int BM, int BN, int WAVES_N, int WAVES_M>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate is 6 bits");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Wait until at most `ahead` tiles (PW DMA instructions each) of this wave are still in flight.
+template <int PW, int MAXAHEAD>
+__device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
+    if constexpr (MAXAHEAD == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (ahead >= MAXAHEAD) wait_vmcnt<(PW * MAXAHEAD < 64 ? PW * MAXAHEAD : 63)>();
+        else wait_tiles_in_flight<PW, MAXAHEAD - 1>(ahead);
+    }
+}
+
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split) {
     static_assert(WAVES_N * WAVES_M == 4, "4 waves");
     constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
     constexpr int TN = WN / 16, TM = WM / 16;             // 16x16 MFMA tiles per wave
+    static_assert(TN >= 1 && TM >= 1, "wave tile");
     constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128;
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int A_GROUPS = BN / 8, B_GROUPS = BM / 8;   // 8-row x 128-B pieces = one DMA each
+    constexpr int PIECES = A_GROUPS + B_GROUPS;
+    constexpr int PW = (PIECES + 3) / 4;                  // DMA instructions per wave per tile (uniform)
+    constexpr int AHEAD = STAGES - 1;                     // tiles kept in flight
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int kbeg = blockIdx.z * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
-    const int ntiles = (kend - kbeg) / BK;
+    const int ntiles = max(0, (kend - kbeg) / BK);
 
     // per-lane DMA source: row (lane>>3) of the 8-row piece, chunk position lane&7
     const int dma_r = lane >> 3, dma_pos = lane & 7;
-
-    auto stage = [&](int t, int buf) {
+    // source row pointers of this wave's PW pieces (k offset added per tile)
+    const bf16* src_row[PW];
+    int lds_off[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        int p = wave + i * 4;
+        if (p >= PIECES) p -= PIECES;                     // duplicate piece keeps the per-wave count uniform
+        const bool is_b = p >= A_GROUPS;
+        const int grp = is_b ? p - A_GROUPS : p;
+        const int r = grp * 8 + dma_r;
+        const int chunk = dma_pos ^ ((r >> 1) & 7);
+        if (is_b) src_row[i] = x + (int64_t)min(m0 + r, M - 1) * x_stride + chunk * 8;
+        else src_row[i] = w + (int64_t)min(n0 + r, N - 1) * K + chunk * 8;
+        lds_off[i] = (is_b ? A_BYTES : 0) + grp * 1024;
+    }
+    auto stage = [&](int t) {
         const int k0 = kbeg + t * BK;
-        char* base = smem + buf * STAGE_BYTES;
+        char* base = smem + (t % STAGES) * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < (A_GROUPS + 3) / 4; ++i) {
-            const int grp = wave + i * 4;
-            if (grp < A_GROUPS) {
-                const int r = grp * 8 + dma_r;
-                const int chunk = dma_pos ^ ((r >> 1) & 7);
-                const int gr = min(n0 + r, N - 1);
-                const bf16* src = w + (int64_t)gr * K + k0 + chunk * 8;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(base + grp * 1024), 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < (B_GROUPS + 3) / 4; ++i) {
-            const int grp = wave + i * 4;
-            if (grp < B_GROUPS) {
-                const int r = grp * 8 + dma_r;
-                const int chunk = dma_pos ^ ((r >> 1) & 7);
-                const int gr = min(m0 + r, M - 1);
-                const bf16* src = x + (int64_t)gr * x_stride + k0 + chunk * 8;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(base + A_BYTES + grp * 1024), 16, 0, 0);
-            }
-        }
+        for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[i] + k0), (LDS_AS void*)(base + lds_off[i]), 16, 0, 0);
     };
 
     f32x4 acc[TN][TM];
@@ -75,12 +98,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
-    if (ntiles > 0) stage(0, 0);
+    for (int t = 0; t < AHEAD && t < ntiles; ++t) stage(t);
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
-        const char* a_base = smem + (t & 1) * STAGE_BYTES;
+        // tiles t+1 .. min(t+AHEAD-1, ntiles-1) may stay in flight; tile t must have landed
+        wait_tiles_in_flight<PW, (AHEAD > 0 ? AHEAD - 1 : 0)>(min(AHEAD - 1, ntiles - 1 - t));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + AHEAD < ntiles) stage(t + AHEAD);          // slot (t-1) % STAGES: consumed before this barrier
+        const char* a_base = smem + (t % STAGES) * STAGE_BYTES;
         const char* b_base = a_base + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -131,31 +157,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     }
 }
 
-template <int BM, int BN, int WAVES_N, int WAVES_M>
-static void launch_gemm(const bf16* x, int64_t xs, const bf16* w, const bf16* bias, bf16* y, int64_t ys, float* partials,
-                        int M, int N, int K, int split_k, hipStream_t st) {
-    constexpr int smem = 2 * (BM + BN) * 128;
+namespace {
+struct GemmArgs {
+    const bf16 *x, *w, *bias;
+    bf16* y;
+    float* partials;
+    int64_t xs, ys;
+    int M, N, K, split_k;
+    hipStream_t st;
+};
+
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
+void launch_gemm(const GemmArgs& a) {
+    constexpr int smem = STAGES * (BM + BN) * 128;
+    static_assert(smem <= 160 * 1024, "LDS");
     static bool configured = false;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES>;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
     }
-    const int ktiles = K / BK;
-    const int k_per_split = (int)nvh_cdiv(ktiles, split_k) * BK;
-    dim3 grid((unsigned)nvh_cdiv(N, BN), (unsigned)nvh_cdiv(M, BM), (unsigned)split_k);
-    kern<<<grid, 256, smem, st>>>(x, xs, w, bias, y, ys, partials, M, N, K, k_per_split);
+    const int ktiles = a.K / BK;
+    const int k_per_split = (int)nvh_cdiv(ktiles, a.split_k) * BK;
+    dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
+    kern<<<grid, 256, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split);
 }
+
+// Tile choice: the largest tile whose grid (x split_k) still gives every CU a workgroup.
+enum Tile { T16x128, T32x128, T64x128, T64x64, T128x64, T128x128 };
+Tile pick_tile(int64_t M, int64_t N, int split_k) {
+    if (M <= 16) return T16x128;
+    if (M <= 32) return T32x128;
+    auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
+    if (M <= 64) return T64x128;
+    if (wgs(128, 128) >= 200) return T128x128;
+    if (wgs(128, 64) >= 200) return T128x64;
+    return T64x64;
+}
+int tile_bm(Tile t) { return t == T16x128 ? 16 : t == T32x128 ? 32 : (t == T64x128 || t == T64x64) ? 64 : 128; }
+int tile_bn(Tile t) { return (t == T64x64 || t == T128x64) ? 64 : 128; }
+}  // namespace
 
 extern "C" int64_t nvh_gemm_workspace_bytes(int64_t M, int64_t N, int32_t split_k) {
     return split_k > 1 ? (int64_t)split_k * M * N * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K) {
-    // Enough workgroups to cover 256 CUs, at least 4 k-tiles (256 k) per split, at most 16 slabs.
-    const int64_t bm = M <= 16 ? 16 : M <= 32 ? 32 : M <= 64 ? 64 : 128;
-    const int64_t tiles = nvh_cdiv(N, 128) * nvh_cdiv(M, bm);
-    if (tiles >= 192) return 1;
+    // Split only when even the smallest tile leaves most CUs idle: enough workgroups for 256 CUs,
+    // at least 4 k-tiles (256 k) per split, at most 16 slabs.
+    const Tile t = pick_tile(M, N, 1);
+    const int64_t tiles = nvh_cdiv(N, tile_bn(t)) * nvh_cdiv(M, tile_bm(t));
+    if (tiles >= 160) return 1;
     int64_t s = nvh_cdiv(256, tiles);
     const int64_t kmax = K / 256 > 1 ? K / 256 : 1;
     if (s > kmax) s = kmax;
@@ -181,18 +233,16 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
         NVH_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0, NVH_EINVAL, "nvh_gemm_bf16_nt: bias must be 8-byte aligned");
     }
     if (M == 0) return NVH_OK;
-    float* partials = split_k > 1 ? workspace : nullptr;
-    hipStream_t st = (hipStream_t)stream;
-    const bf16 *xp = (const bf16*)x, *wp = (const bf16*)w, *bp = (const bf16*)bias;
-    bf16* yp = (bf16*)y;
-    if (M <= 16)
-        launch_gemm<16, 128, 4, 1>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
-    else if (M <= 32)
-        launch_gemm<32, 128, 4, 1>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
-    else if (M <= 64)
-        launch_gemm<64, 128, 2, 2>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
-    else
-        launch_gemm<128, 128, 2, 2>(xp, x_row_stride, wp, bp, yp, y_row_stride, partials, (int)M, (int)N, (int)K, split_k, st);
+    GemmArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)y, split_k > 1 ? workspace : nullptr,
+               x_row_stride, y_row_stride, (int)M, (int)N, (int)K, split_k, (hipStream_t)stream};
+    switch (pick_tile(M, N, split_k)) {
+        case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;
+        case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
+        case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
+        case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;
+        case T128x64: launch_gemm<128, 64, 2, 2, 4>(a); break;
+        case T128x128: launch_gemm<128, 128, 2, 2, 2>(a); break;
+    }
     NVH_CHECK_LAUNCH("gemm_bf16_nt");
     return NVH_OK;
 }
