@@ -149,18 +149,21 @@ int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int6
 
 /* ---- K8: sampling.  layers/sampler.py:41-81.
  * nvh_sample: p = softmax(f32(logits)/T); token = argmax(p / max(E,1e-10)), E ~ Exp(1) from
- * a counter-based generator keyed by (seed, offset, row, column).
+ * a counter-based generator keyed by (seed, offset, row, column); evaluated as
+ * argmax(logits/T - log(max(E,1e-10))), which has the same maximiser.  Rows are cut into slices
+ * scanned by separate workgroups; `workspace` (nvh_sample_workspace_bytes) holds their candidates.
  * nvh_sample_with_noise: same with the noise tensor supplied (fp32 [rows, vocab]).
  * nvh_argmax: lowest index of the row maximum (the pre-sampler greedy token).
  * logits bf16 or fp32 (logits_is_f32), row stride in elements; out int64 [rows]. */
+int64_t nvh_sample_workspace_bytes(int64_t rows, int64_t vocab);   /* 0: no workspace needed */
 int32_t nvh_sample(const void* logits, int32_t logits_is_f32, int64_t row_stride, const float* temperatures,
                    int64_t* out, int64_t rows, int64_t vocab, uint64_t seed, uint64_t offset,
-                   nvh_stream_t stream);
+                   void* workspace, nvh_stream_t stream);
 int32_t nvh_sample_with_noise(const void* logits, int32_t logits_is_f32, int64_t row_stride,
                               const float* temperatures, const float* noise, int64_t* out,
-                              int64_t rows, int64_t vocab, nvh_stream_t stream);
+                              int64_t rows, int64_t vocab, void* workspace, nvh_stream_t stream);
 int32_t nvh_argmax(const void* logits, int32_t logits_is_f32, int64_t row_stride, int64_t* out,
-                   int64_t rows, int64_t vocab, nvh_stream_t stream);
+                   int64_t rows, int64_t vocab, void* workspace, nvh_stream_t stream);
 
 /* ---- whole-model executor: the layer loop of models/qwen3.py:401-441 (Qwen3Model.forward) and
  * compute_logits (:509-533), issued from native code so one call enqueues every kernel of a step

@@ -156,22 +156,43 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
 }
 
 // One workgroup of 128 threads per (sequence, query head): merge the per-range partials.
+// The (max, sum) pairs are fetched by one load per thread and turned into per-range weights in LDS;
+// the output columns are then accumulated with independent loads (ranges that saw no key are skipped).
 __global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
                                                                   const float* __restrict__ ws_ml,
                                                                   bf16* __restrict__ out, int num_splits) {
+    __shared__ float sm_w[256];
+    __shared__ float sm_red[2];
     const int64_t bh = blockIdx.x;
-    const int d = threadIdx.x;
-    float M = -INFINITY;
-    for (int s = 0; s < num_splits; ++s) M = fmaxf(M, ws_ml[(bh * num_splits + s) * 2]);
+    const int tid = threadIdx.x;
+    float m_loc = -INFINITY;
+    for (int s = tid; s < num_splits; s += 128) m_loc = fmaxf(m_loc, ws_ml[(bh * num_splits + s) * 2]);
+    m_loc = wave_max(m_loc);
+    if ((tid & 63) == 0) sm_red[tid >> 6] = m_loc;
+    __syncthreads();
+    const float M = fmaxf(sm_red[0], sm_red[1]);
     const float mu = (M == -INFINITY) ? 0.f : M;
-    float L = 0.f, A = 0.f;
-    for (int s = 0; s < num_splits; ++s) {
+    float l_loc = 0.f;
+    for (int s = tid; s < num_splits; s += 128) {
         const int64_t slab = bh * num_splits + s;
-        const float sc = __builtin_amdgcn_exp2f(ws_ml[slab * 2] - mu);
-        L += ws_ml[slab * 2 + 1] * sc;
-        A += ws_acc[slab * 128 + d] * sc;
+        const float l = ws_ml[slab * 2 + 1];
+        const float wgt = l > 0.f ? __builtin_amdgcn_exp2f(ws_ml[slab * 2] - mu) : 0.f;
+        sm_w[s] = wgt;
+        l_loc += l * wgt;
     }
-    out[bh * 128 + d] = f2bf(L > 0.f ? A / L : 0.f);
+    l_loc = wave_sum(l_loc);
+    __syncthreads();
+    if ((tid & 63) == 0) sm_red[tid >> 6] = l_loc;
+    __syncthreads();
+    const float L = sm_red[0] + sm_red[1];
+    float A = 0.f;
+    const float* acc = ws_acc + bh * num_splits * 128 + tid;
+#pragma unroll 8
+    for (int s = 0; s < num_splits; ++s) {
+        const float wgt = sm_w[s];
+        if (wgt != 0.f) A += acc[(int64_t)s * 128] * wgt;
+    }
+    out[bh * 128 + tid] = f2bf(L > 0.f ? A / L : 0.f);
 }
 
 extern "C" int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t head_dim, int32_t num_splits) {

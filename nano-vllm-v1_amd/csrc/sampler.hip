@@ -1,10 +1,13 @@
-// Row-wise argmax and temperature sampling over the vocabulary (HBM-bound passes over the
-// logits).  One 1024-thread workgroup per row; 16-byte loads; (value, index) reductions keep
-// the LOWEST index among equal values, like a sequential scan.
+// Row-wise argmax and temperature sampling over the vocabulary: ONE pass over the logits, rows cut
+// into slices so that ~1024 workgroups stream them; (value, index) reductions keep the LOWEST
+// index among equal values, like a sequential scan.
 //
-// Sampling uses the exponential-race form of the reference: token = argmax_i p_i / E_i with
-// E_i ~ Exp(1), p = softmax(logits / T):
-// score_i = (exp(z_i - max z) / sum_j exp(z_j - max z)) / max(E_i, 1e-10), z = logits / T, in fp32.
+// Sampling is the reference's exponential race, token = argmax_i p_i / E_i with E_i ~ Exp(1) and
+// p = softmax(logits / T), evaluated in the log domain: log(p_i / E_i) = z_i - log E_i - logsumexp(z),
+// z = logits / T.  The last term is a per-row constant, so score_i = z_i - log(max(E_i, 1e-10)) has the
+// same argmax and needs neither the row maximum nor the softmax denominator (no extra passes, no
+// underflow).  It can differ from the reference's fp32 evaluation only when two candidates are within
+// rounding of each other.
 #include "common.h"
 
 struct ValIdx {
@@ -90,96 +93,123 @@ __device__ __forceinline__ void philox(uint32_t (&c)[4], uint32_t k0, uint32_t k
 }
 
 // MODE 0: argmax   MODE 1: sample with generated noise   MODE 2: sample with supplied noise
+// Grid (slices, rows): every workgroup scans one slice of one row and leaves its best candidate in
+// `cand` (or in `out` directly when there is one slice); sample_final_kernel picks among slices.
 template <bool F32, int MODE>
-__global__ __launch_bounds__(1024) void sample_kernel(const void* __restrict__ logits, int64_t row_stride,
-                                                      const float* __restrict__ temps, const float* __restrict__ noise,
-                                                      int64_t* __restrict__ out, int64_t vocab, uint64_t seed, uint64_t offset,
-                                                      bool vec_ok) {
-    __shared__ ValIdx sm_vi[16];
-    __shared__ float sm_f[16];
-    const int64_t row = blockIdx.x;
+__global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restrict__ logits, int64_t row_stride,
+                                                           const float* __restrict__ temps, const float* __restrict__ noise,
+                                                           int64_t* __restrict__ out, ValIdx* __restrict__ cand, int64_t vocab,
+                                                           int64_t slice_len, uint64_t seed, uint64_t offset, bool vec_ok) {
+    __shared__ ValIdx sm_vi[4];
+    const int64_t row = blockIdx.y;
+    const int64_t lo = (int64_t)blockIdx.x * slice_len;
+    const int64_t hi = min(vocab, lo + slice_len);
     const void* rp = F32 ? (const void*)((const float*)logits + row * row_stride) : (const void*)((const bf16*)logits + row * row_stride);
-    float v[4];
+    float t = 1.f;
+    if constexpr (MODE != 0) t = temps[row];
     ValIdx best{-INFINITY, (int64_t)0x7fffffffffffffffLL};
-    if constexpr (MODE == 0) {
-        for (int64_t i = (int64_t)threadIdx.x * 4; i < vocab; i += 4096) {
-            load4<F32>(rp, i, vocab, vec_ok, v);
+    // two independent 4-element groups per trip keep two loads in flight per lane
+    for (int64_t i0 = lo + (int64_t)threadIdx.x * 4; i0 < hi; i0 += 2048) {
+        float v[2][4];
+        load4<F32>(rp, i0, hi, vec_ok, v[0]);
+        const int64_t i1 = i0 + 1024;
+        if (i1 < hi) load4<F32>(rp, i1, hi, vec_ok, v[1]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (i + e < vocab) best = better(best, ValIdx{v[e], i + e});
-        }
-    } else {
-        const float t = temps[row];
-        // one pass: per-thread online (max, sum of exp), merged across the workgroup
-        float mt = -INFINITY, st = 0.f;
-        for (int64_t i = (int64_t)threadIdx.x * 4; i < vocab; i += 4096) {
-            load4<F32>(rp, i, vocab, vec_ok, v);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (i + e < vocab) {
-                    const float z = v[e] / t;
-                    const float mn = fmaxf(mt, z);
-                    st = st * expf(mt - mn) + expf(z - mn);
-                    mt = mn;
-                }
-        }
-        const float mx = block_max(mt, sm_f);
-        const float denom = block_sum(mt == -INFINITY ? 0.f : st * expf(mt - mx), sm_f);
-        for (int64_t i = (int64_t)threadIdx.x * 4; i < vocab; i += 4096) {
-            load4<F32>(rp, i, vocab, vec_ok, v);
-            float e4[4];
+        for (int u = 0; u < 2; ++u) {
+            const int64_t i = u ? i1 : i0;
+            if (i >= hi) continue;
+            float e4[4] = {1.f, 1.f, 1.f, 1.f};
             if constexpr (MODE == 1) {
                 uint32_t c[4] = {(uint32_t)(i >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)};
                 philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u = ((float)(c[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
-                    e4[e] = -logf(u);
-                }
-            } else {
+                for (int e = 0; e < 4; ++e) e4[e] = -logf(((float)(c[e] >> 8) + 0.5f) * (1.0f / 16777216.0f));
+            } else if constexpr (MODE == 2) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) e4[e] = (i + e < vocab) ? noise[row * vocab + i + e] : 1.f;
+                for (int e = 0; e < 4; ++e) e4[e] = (i + e < hi) ? noise[row * vocab + i + e] : 1.f;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (i + e < vocab) {
-                    const float p = expf(v[e] / t - mx) / denom;
-                    best = better(best, ValIdx{p / fmaxf(e4[e], 1e-10f), i + e});
+                if (i + e < hi) {
+                    float sc = v[u][e];
+                    if constexpr (MODE != 0) sc = v[u][e] / t - logf(fmaxf(e4[e], 1e-10f));
+                    best = better(best, ValIdx{sc, i + e});
                 }
         }
     }
     best = block_argmax(best, sm_vi);
+    if (threadIdx.x == 0) {
+        if (gridDim.x == 1) out[row] = best.i;
+        else cand[row * gridDim.x + blockIdx.x] = best;
+    }
+}
+
+__global__ __launch_bounds__(64) void sample_final_kernel(const ValIdx* __restrict__ cand, int64_t* __restrict__ out, int slices) {
+    const int64_t row = blockIdx.x;
+    ValIdx best{-INFINITY, (int64_t)0x7fffffffffffffffLL};
+    for (int s = threadIdx.x; s < slices; s += 64) best = better(best, cand[row * slices + s]);
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        ValIdx o;
+        o.v = __shfl_xor(best.v, sft, 64);
+        o.i = __shfl_xor(best.i, sft, 64);
+        best = better(best, o);
+    }
     if (threadIdx.x == 0) out[row] = best.i;
+}
+
+static int sample_slices(int64_t rows, int64_t vocab) {
+    // ~1024 workgroups in total, at least 2048 elements per slice, at most 64 slices
+    int64_t s = 1024 / (rows > 0 ? rows : 1);
+    const int64_t cap = vocab / 2048 > 1 ? vocab / 2048 : 1;
+    if (s > cap) s = cap;
+    if (s > 64) s = 64;
+    return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int64_t nvh_sample_workspace_bytes(int64_t rows, int64_t vocab) {
+    const int s = sample_slices(rows, vocab);
+    return s > 1 ? rows * s * (int64_t)sizeof(ValIdx) : 0;
 }
 
 template <int MODE>
 static int32_t launch_sample(const char* name, const void* logits, int32_t is_f32, int64_t row_stride, const float* temps,
                              const float* noise, int64_t* out, int64_t rows, int64_t vocab, uint64_t seed, uint64_t offset,
-                             nvh_stream_t stream) {
+                             void* workspace, nvh_stream_t stream) {
     NVH_REQUIRE(logits && out && (MODE == 0 || temps) && (MODE != 2 || noise), NVH_EINVAL, "%s: null pointer", name);
-    NVH_REQUIRE(vocab > 0 && rows >= 0, NVH_EINVAL, "%s: bad shape", name);
+    NVH_REQUIRE(vocab > 0 && rows >= 0 && rows <= 65535, NVH_EINVAL, "%s: bad shape", name);
     NVH_REQUIRE(((uintptr_t)logits & (is_f32 ? 3 : 1)) == 0, NVH_EINVAL, "%s: logits misaligned", name);
-    // rows that do not start on a 4-element boundary are read with scalar loads
-    const bool vec_ok = row_stride % 4 == 0 && ((uintptr_t)logits & (is_f32 ? 15 : 7)) == 0;
     if (rows == 0) return NVH_OK;
+    const int slices = sample_slices(rows, vocab);
+    NVH_REQUIRE(slices == 1 || (workspace && nvh_aligned16(workspace)), NVH_EINVAL, "%s: workspace of nvh_sample_workspace_bytes() needed", name);
+    // rows that do not start on a 4-element boundary are read with scalar loads
+    int64_t slice_len = (nvh_cdiv(vocab, slices) + 3) & ~int64_t(3);
+    const bool vec_ok = row_stride % 4 == 0 && ((uintptr_t)logits & (is_f32 ? 15 : 7)) == 0;
+    dim3 grid((unsigned)slices, (unsigned)rows);
+    hipStream_t st = (hipStream_t)stream;
     if (is_f32)
-        sample_kernel<true, MODE><<<(unsigned)rows, 1024, 0, (hipStream_t)stream>>>(logits, row_stride, temps, noise, out, vocab, seed, offset, vec_ok);
+        sample_slice_kernel<true, MODE><<<grid, 256, 0, st>>>(logits, row_stride, temps, noise, out, (ValIdx*)workspace, vocab, slice_len, seed, offset, vec_ok);
     else
-        sample_kernel<false, MODE><<<(unsigned)rows, 1024, 0, (hipStream_t)stream>>>(logits, row_stride, temps, noise, out, vocab, seed, offset, vec_ok);
+        sample_slice_kernel<false, MODE><<<grid, 256, 0, st>>>(logits, row_stride, temps, noise, out, (ValIdx*)workspace, vocab, slice_len, seed, offset, vec_ok);
     NVH_CHECK_LAUNCH(name);
+    if (slices > 1) {
+        sample_final_kernel<<<(unsigned)rows, 64, 0, st>>>((const ValIdx*)workspace, out, slices);
+        NVH_CHECK_LAUNCH(name);
+    }
     return NVH_OK;
 }
 
 extern "C" int32_t nvh_argmax(const void* logits, int32_t logits_is_f32, int64_t row_stride, int64_t* out, int64_t rows,
-                              int64_t vocab, nvh_stream_t stream) {
-    return launch_sample<0>("nvh_argmax", logits, logits_is_f32, row_stride, nullptr, nullptr, out, rows, vocab, 0, 0, stream);
+                              int64_t vocab, void* workspace, nvh_stream_t stream) {
+    return launch_sample<0>("nvh_argmax", logits, logits_is_f32, row_stride, nullptr, nullptr, out, rows, vocab, 0, 0, workspace, stream);
 }
 extern "C" int32_t nvh_sample(const void* logits, int32_t logits_is_f32, int64_t row_stride, const float* temperatures,
-                              int64_t* out, int64_t rows, int64_t vocab, uint64_t seed, uint64_t offset, nvh_stream_t stream) {
-    return launch_sample<1>("nvh_sample", logits, logits_is_f32, row_stride, temperatures, nullptr, out, rows, vocab, seed, offset, stream);
+                              int64_t* out, int64_t rows, int64_t vocab, uint64_t seed, uint64_t offset, void* workspace,
+                              nvh_stream_t stream) {
+    return launch_sample<1>("nvh_sample", logits, logits_is_f32, row_stride, temperatures, nullptr, out, rows, vocab, seed, offset, workspace, stream);
 }
 extern "C" int32_t nvh_sample_with_noise(const void* logits, int32_t logits_is_f32, int64_t row_stride,
                                          const float* temperatures, const float* noise, int64_t* out, int64_t rows,
-                                         int64_t vocab, nvh_stream_t stream) {
-    return launch_sample<2>("nvh_sample_with_noise", logits, logits_is_f32, row_stride, temperatures, noise, out, rows, vocab, 0, 0, stream);
+                                         int64_t vocab, void* workspace, nvh_stream_t stream) {
+    return launch_sample<2>("nvh_sample_with_noise", logits, logits_is_f32, row_stride, temperatures, noise, out, rows, vocab, 0, 0, workspace, stream);
 }

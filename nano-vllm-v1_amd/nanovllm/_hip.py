@@ -35,9 +35,10 @@ SIGNATURES = {
     "nvh_attn_decode": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
     "nvh_attn_decode_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_decode_suggest_splits": (i32, [i64, i64, i64]),
-    "nvh_sample": (i32, [vp, i32, i64, vp, vp, i64, i64, u64, u64, vp]),
-    "nvh_sample_with_noise": (i32, [vp, i32, i64, vp, vp, vp, i64, i64, vp]),
-    "nvh_argmax": (i32, [vp, i32, i64, vp, i64, i64, vp]),
+    "nvh_sample_workspace_bytes": (i64, [i64, i64]),
+    "nvh_sample": (i32, [vp, i32, i64, vp, vp, i64, i64, u64, u64, vp, vp]),
+    "nvh_sample_with_noise": (i32, [vp, i32, i64, vp, vp, vp, i64, i64, vp, vp]),
+    "nvh_argmax": (i32, [vp, i32, i64, vp, i64, i64, vp, vp]),
     # struct pointers (nvh_qwen3_model*, nvh_step*) travel as void*; layouts are in nanovllm/native.py
     "nvh_qwen3_workspace_bytes": (i64, [vp, i64, i64, i32]),
     "nvh_qwen3_forward": (i32, [vp, vp, vp, vp, i64, vp]),

@@ -233,10 +233,17 @@ def _logits_args(logits):
     raise TypeError(f"logits dtype {logits.dtype} unsupported")
 
 
+def _sample_ws(logits):
+    n = _hip.lib().nvh_sample_workspace_bytes(logits.shape[0], logits.shape[1])
+    return torch.empty(n, dtype=torch.uint8, device=logits.device) if n else None
+
+
 def argmax(logits: torch.Tensor) -> torch.Tensor:
     f = _logits_args(logits)
     out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
-    _hip.call("nvh_argmax", logits.data_ptr(), f, logits.stride(0), out.data_ptr(), logits.shape[0], logits.shape[1], _stream())
+    ws = _sample_ws(logits)
+    _hip.call("nvh_argmax", logits.data_ptr(), f, logits.stride(0), out.data_ptr(), logits.shape[0], logits.shape[1],
+              _p(ws), _stream())
     return out
 
 
@@ -244,8 +251,9 @@ def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: 
     f = _logits_args(logits)
     assert temperatures.dtype == torch.float32 and temperatures.numel() == logits.shape[0]
     out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    ws = _sample_ws(logits)
     _hip.call("nvh_sample", logits.data_ptr(), f, logits.stride(0), temperatures.data_ptr(), out.data_ptr(),
-              logits.shape[0], logits.shape[1], seed, offset, _stream())
+              logits.shape[0], logits.shape[1], seed, offset, _p(ws), _stream())
     return out
 
 
@@ -253,6 +261,7 @@ def sample_with_noise(logits: torch.Tensor, temperatures: torch.Tensor, noise: t
     f = _logits_args(logits)
     assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == logits.shape
     out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    ws = _sample_ws(logits)
     _hip.call("nvh_sample_with_noise", logits.data_ptr(), f, logits.stride(0), temperatures.data_ptr(), noise.data_ptr(),
-              out.data_ptr(), logits.shape[0], logits.shape[1], _stream())
+              out.data_ptr(), logits.shape[0], logits.shape[1], _p(ws), _stream())
     return out
