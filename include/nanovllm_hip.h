@@ -129,9 +129,15 @@ int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride,
                         const void* k, const void* v, int64_t kv_token_stride,
                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                         const int32_t* block_tables, int64_t table_stride,
-                        int64_t batch, int64_t max_seqlen_q, int64_t total_q,
+                        int64_t batch, int64_t max_seqlen_q, int64_t max_seqlen_k, int64_t total_q,
                         int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                        float softmax_scale, void* out, nvh_stream_t stream);
+                        float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                        nvh_stream_t stream);
+/* num_splits > 1 cuts every sequence's keys into that many ranges of whole 64-key tiles handled by
+ * separate workgroups (fills the chip when a chunk has few query blocks); needs `workspace`. */
+int64_t nvh_attn_varlen_workspace_bytes(int64_t total_q, int64_t num_q_heads, int64_t head_dim, int32_t num_splits);
+int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
+                                       int64_t max_seqlen_k);
 
 /* ---- K3: paged decode attention, one query per sequence.
  * layers/attention.py:222-234 (flash_attn_with_kvcache).  q [B,Hq,D]; context_lens int32 [B]

@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
             const int toff = u * 16 + rowid;
             valid[u] = base + toff < end;
             const int64_t off = ((slot0 + (valid[u] ? toff : 0)) * hkv + kvh) * 128 + c * 8;
-            kf[u] = *reinterpret_cast<const bf16x8*>(kc + off);
-            vf[u] = *reinterpret_cast<const bf16x8*>(vc + off);
+            kf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kc + off));   // streamed once
+            vf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vc + off));
         }
         float s[G][4];
 #pragma unroll
@@ -155,44 +155,61 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
     }
 }
 
-// One workgroup of 128 threads per (sequence, query head): merge the per-range partials.
-// The (max, sum) pairs are fetched by one load per thread and turned into per-range weights in LDS;
-// the output columns are then accumulated with independent loads (ranges that saw no key are skipped).
-__global__ __launch_bounds__(128) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
+// Merge per-range partials: ONE WAVE per output row (sequence/token x query head), 4 rows per workgroup,
+// no LDS and no barriers.  Lane s fetches the (max, sum) of range s (<= 64 ranges per pass), the wave
+// reduces them with shuffles, then every lane accumulates its 2 output columns over the ranges with
+// independent 8-byte loads; ranges that saw no key (sum 0) are skipped.
+__global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
                                                                   const float* __restrict__ ws_ml,
-                                                                  bf16* __restrict__ out, int num_splits) {
-    __shared__ float sm_w[256];
-    __shared__ float sm_red[2];
-    const int64_t bh = blockIdx.x;
-    const int tid = threadIdx.x;
+                                                                  bf16* __restrict__ out, int num_splits, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= rows) return;
+    const f32x2* ml = reinterpret_cast<const f32x2*>(ws_ml) + bh * num_splits;
+    // pass 1: row maximum over all ranges
     float m_loc = -INFINITY;
-    for (int s = tid; s < num_splits; s += 128) m_loc = fmaxf(m_loc, ws_ml[(bh * num_splits + s) * 2]);
-    m_loc = wave_max(m_loc);
-    if ((tid & 63) == 0) sm_red[tid >> 6] = m_loc;
-    __syncthreads();
-    const float M = fmaxf(sm_red[0], sm_red[1]);
+    for (int s0 = 0; s0 < num_splits; s0 += 64) {
+        const int s = s0 + lane;
+        if (s < num_splits) {
+            const f32x2 v = ml[s];
+            if (v[1] > 0.f) m_loc = fmaxf(m_loc, v[0]);
+        }
+    }
+    const float M = wave_max(m_loc);
     const float mu = (M == -INFINITY) ? 0.f : M;
-    float l_loc = 0.f;
-    for (int s = tid; s < num_splits; s += 128) {
-        const int64_t slab = bh * num_splits + s;
-        const float l = ws_ml[slab * 2 + 1];
-        const float wgt = l > 0.f ? __builtin_amdgcn_exp2f(ws_ml[slab * 2] - mu) : 0.f;
-        sm_w[s] = wgt;
-        l_loc += l * wgt;
+    float L = 0.f;
+    f32x2 A = {0.f, 0.f};
+    const f32x2* acc = reinterpret_cast<const f32x2*>(ws_acc + bh * num_splits * 128) + lane;
+    for (int s0 = 0; s0 < num_splits; s0 += 64) {
+        const int s = s0 + lane;
+        float wgt = 0.f, l = 0.f;
+        if (s < num_splits) {
+            const f32x2 v = ml[s];
+            l = v[1];
+            wgt = l > 0.f ? __builtin_amdgcn_exp2f(v[0] - mu) : 0.f;
+        }
+        L += l * wgt;
+        const int n = min(64, num_splits - s0);
+#pragma unroll 4
+        for (int j = 0; j < n; ++j) {
+            const float wj = __shfl(wgt, j, 64);
+            if (wj != 0.f) {                                   // wave-uniform
+                const f32x2 v = acc[(int64_t)(s0 + j) * 64];
+                A[0] += v[0] * wj;
+                A[1] += v[1] * wj;
+            }
+        }
     }
-    l_loc = wave_sum(l_loc);
-    __syncthreads();
-    if ((tid & 63) == 0) sm_red[tid >> 6] = l_loc;
-    __syncthreads();
-    const float L = sm_red[0] + sm_red[1];
-    float A = 0.f;
-    const float* acc = ws_acc + bh * num_splits * 128 + tid;
-#pragma unroll 8
-    for (int s = 0; s < num_splits; ++s) {
-        const float wgt = sm_w[s];
-        if (wgt != 0.f) A += acc[(int64_t)s * 128] * wgt;
-    }
-    out[bh * 128 + tid] = f2bf(L > 0.f ? A / L : 0.f);
+    L = wave_sum(L);
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    bf16x2 o = {f2bf(A[0] * inv), f2bf(A[1] * inv)};
+    *reinterpret_cast<bf16x2*>(out + bh * 128 + lane * 2) = o;
+}
+
+int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits, hipStream_t st) {
+    attn_decode_combine_kernel<<<(unsigned)nvh_cdiv(rows, 4), 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, rows);
+    NVH_CHECK_LAUNCH("attn_combine");
+    return NVH_OK;
 }
 
 extern "C" int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t head_dim, int32_t num_splits) {
@@ -201,9 +218,9 @@ extern "C" int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_
 }
 
 extern "C" int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int64_t max_context) {
-    // Aim for >= 1024 workgroups (4 per CU) while keeping >= 128 keys per range.
+    // Aim for >= 512 workgroups (2 per CU) while keeping >= 128 keys per range.
     const int64_t wgs = batch * num_kv_heads;
-    int64_t want = nvh_cdiv(1024, wgs > 0 ? wgs : 1);
+    int64_t want = nvh_cdiv(512, wgs > 0 ? wgs : 1);
     const int64_t cap = max_context / 128 > 1 ? max_context / 128 : 1;
     if (want > cap) want = cap;
     if (want > 64) want = 64;
@@ -247,8 +264,7 @@ extern "C" int32_t nvh_attn_decode(const void* q, int64_t q_token_stride, const 
 #undef LAUNCH_DEC
     NVH_CHECK_LAUNCH("attn_decode");
     if (num_splits > 1) {
-        attn_decode_combine_kernel<<<(unsigned)(batch * num_q_heads), 128, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits);
-        NVH_CHECK_LAUNCH("attn_decode_combine");
+        return nvh_launch_attn_combine(ws_acc, ws_ml, out, batch * num_q_heads, num_splits, st);
     }
     return NVH_OK;
 }

@@ -13,8 +13,13 @@
 //         tile ARE the B fragment of k-step s of the next product (no lane movement);
 //   O^T += V^T . P^T A = V^T read straight from the row-major V tile with the transposing
 //                    LDS read (ds_read_b64_tr_b16), k order matched to the P fragment.
-// K/V tiles go global -> registers -> LDS; the loads for tile t+1 are issued before the
-// MFMA work of tile t and written to LDS after it.
+// K/V tiles go global -> LDS by 16-byte LDS-DMA (two LDS stages, one barrier per tile): the DMA of
+// tile t+1 runs under the MFMA work of tile t; the swizzles are applied to the per-lane SOURCE
+// address because the DMA writes lane-linear.  Two workgroups fit a CU (<= 256 registers, 64 KB
+// LDS), so one's softmax overlaps the other's MFMAs.
+// Long key ranges can be cut into `num_splits` ranges of whole tiles (gridDim.z = B * splits):
+// each range leaves an unnormalised fp32 partial + (max, sum) and the decode path's combine
+// kernel merges them - this is what fills the chip when a chunk has few query blocks.
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
@@ -27,16 +32,18 @@ __device__ __forceinline__ int k_off(int row, int ch) {          // K tile
 }
 
 template <int G, int RB, bool PAGED>
-__global__ __launch_bounds__(G * RB * 64) void attn_varlen_kernel(
+__global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 ? 2 : 1)) void attn_varlen_kernel(
     const bf16* __restrict__ q, int64_t q_stride, const bf16* __restrict__ kp, const bf16* __restrict__ vp,
     int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
-    const int32_t* __restrict__ tables, int64_t table_stride, int hkv, float scale_log2, bf16* __restrict__ out) {
-    constexpr int NW = G * RB, NT = NW * 64, BQ = 32 * RB;
-    constexpr int LD = 2048 / NT + ((2048 % NT) ? 1 : 0);        // 16-B chunks per thread per tile (K+V)
-    __shared__ __attribute__((aligned(16))) char sm_k[64 * 256];
-    __shared__ __attribute__((aligned(16))) char sm_v[64 * 256];
+    const int32_t* __restrict__ tables, int64_t table_stride, int hkv, float scale_log2, bf16* __restrict__ out,
+    int num_splits, int tiles_per_split, float* __restrict__ ws_acc, float* __restrict__ ws_ml) {
+    constexpr int NW = G * RB, BQ = 32 * RB;
+    constexpr int PIECES = 32;                                   // 1-KiB DMA pieces per K+V tile (4 keys each)
+    constexpr int PW = (PIECES + NW - 1) / NW;                   // pieces per wave (uniform; extras duplicate)
+    constexpr int STAGE = 2 * 64 * 256;                          // K tile + V tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
 
-    const int b = blockIdx.z, kvh = blockIdx.y;
+    const int b = blockIdx.z / num_splits, split = blockIdx.z % num_splits, kvh = blockIdx.y;
     const int q_beg = cu_q[b], lq = cu_q[b + 1] - q_beg;
     const int k_beg = cu_k[b], lk = cu_k[b + 1] - k_beg;
     const int qb0 = blockIdx.x * BQ;
@@ -51,19 +58,12 @@ __global__ __launch_bounds__(G * RB * 64) void attn_varlen_kernel(
     const int qrow_raw = qb0 + rb * 32 + ql;
     const int qrow = min(qrow_raw, lq - 1);
 
-    // keys needed by this workgroup / this wave
+    // key tiles of this workgroup: [kt_beg, kt_end) within the tiles its query block can see
     const int wg_last_key = min(qb0 + BQ, lq) - 1 + shift;
-    const int num_kt = wg_last_key / 64 + 1;
+    const int kt_beg = split * tiles_per_split;
+    const int kt_end = min(wg_last_key / 64 + 1, kt_beg + tiles_per_split);
     const int wave_first_row = min(qb0 + rb * 32, lq - 1);
     const int wave_last_key = min(qb0 + rb * 32 + 31, lq - 1) + shift;
-
-    // Q^T fragments: lane (q = ql, half hh) holds Q[q][16ks + 8hh .. +7]
-    bf16x8 qf[8];
-    {
-        const bf16* qp = q + (int64_t)(q_beg + qrow) * q_stride + (int64_t)h * 128 + 8 * hh;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-    }
 
     f32x16 o[4];
 #pragma unroll
@@ -72,121 +72,127 @@ __global__ __launch_bounds__(G * RB * 64) void attn_varlen_kernel(
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging: chunk id -> (K|V, key, 16-B chunk)
-    bf16x8 stage[LD];
-    auto issue_loads = [&](int kt) {
-        int64_t page_base = 0;
-        if constexpr (PAGED) page_base = (int64_t)tables[(int64_t)b * table_stride + ((kt * 64) >> 8)] * NVH_KV_PAGE;
+    if (kt_beg < kt_end) {
+        // Q^T fragments: lane (q = ql, half hh) holds Q[q][16ks + 8hh .. +7]
+        bf16x8 qf[8];
+        {
+            const bf16* qp = q + (int64_t)(q_beg + qrow) * q_stride + (int64_t)h * 128 + 8 * hh;
 #pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            const int id = i * NT + tid;
-            if (id < 2048) {
-                const int isv = id >> 10, key = (id >> 4) & 63, ch = id & 15;
+            for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+        }
+        // LDS-DMA staging: piece p < 16 -> K keys 4p..4p+3, p >= 16 -> V keys; lane -> (key, chunk position)
+        auto stage = [&](int kt) {
+            char* base = smem + (kt & 1) * STAGE;
+            int64_t page_base = 0;
+            if constexpr (PAGED) page_base = (int64_t)tables[(int64_t)b * table_stride + ((kt * 64) >> 8)] * NVH_KV_PAGE;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                int p = wave + i * NW;
+                if (p >= PIECES) p -= PIECES;
+                const int isv = p >> 4;
+                const int key = (p & 15) * 4 + (lane >> 4), pos = lane & 15;
+                const int ch = isv ? (pos ^ (((key & 3) << 2) | ((key >> 2) & 3))) : (pos ^ (key & 15));
                 const int kk = min(kt * 64 + key, lk - 1);
-                const bf16* base = isv ? vp : kp;
                 int64_t row;
                 if constexpr (PAGED) row = ((page_base + (kk & 255)) * hkv + kvh) * 128;
                 else row = (int64_t)(k_beg + kk) * kv_stride + (int64_t)kvh * 128;
-                stage[i] = *reinterpret_cast<const bf16x8*>(base + row + ch * 8);
+                const bf16* src = (isv ? vp : kp) + row + ch * 8;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(base + p * 1024), 16, 0, 0);
             }
-        }
-    };
-    auto write_lds = [&]() {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) {
-            const int id = i * NT + tid;
-            if (id < 2048) {
-                const int isv = id >> 10, key = (id >> 4) & 63, ch = id & 15;
-                if (isv) *reinterpret_cast<bf16x8*>(sm_v + v_off(key, ch)) = stage[i];
-                else *reinterpret_cast<bf16x8*>(sm_k + k_off(key, ch)) = stage[i];
-            }
-        }
-    };
+        };
 
-    issue_loads(0);
-    for (int kt = 0; kt < num_kt; ++kt) {
-        __syncthreads();                       // previous tile fully consumed
-        write_lds();
-        __syncthreads();
-        if (kt + 1 < num_kt) issue_loads(kt + 1);
-        if (kt * 64 > wave_last_key) continue; // tile entirely above this wave's diagonal (wave-uniform)
+        stage(kt_beg);
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
+            __builtin_amdgcn_s_barrier();                       // ... everyone's have, and tile kt-1 is consumed
+            asm volatile("" ::: "memory");
+            if (kt + 1 < kt_end) stage(kt + 1);
+            if (kt * 64 > wave_last_key) continue;              // tile entirely above this wave's diagonal
+            const char* sm_k = smem + (kt & 1) * STAGE;
+            const char* sm_v = sm_k + 64 * 256;
 
-        // ---- S^T = K . Q^T for the two 32-key halves
-        f32x16 st[2];
+            // ---- S^T = K . Q^T for the two 32-key halves
+            f32x16 st[2];
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
+            for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
-            const int key = t2 * 32 + ql;
+                for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
+                const int key = t2 * 32 + ql;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sm_k + k_off(key, 2 * ks + hh));
-                st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], st[t2], 0, 0, 0);
-            }
-        }
-        // ---- scale, causal mask, online softmax (query on the lane)
-        const bool need_mask = kt * 64 + 63 > wave_first_row + shift;
-        const int vis = qrow + shift;          // last visible key of this lane's query
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = st[t2][r] * scale_log2;
-                if (need_mask) {
-                    const int key = kt * 64 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    s = key > vis ? -INFINITY : s;
+                for (int ks = 0; ks < 8; ++ks) {
+                    const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sm_k + k_off(key, 2 * ks + hh));
+                    st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], st[t2], 0, 0, 0);
                 }
-                st[t2][r] = s;
-                mx = fmaxf(mx, s);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-        m_run = m_new;
-        float psum = 0.f;
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[t2][r] - m_use);
-                psum += p;
-                pb[t2][r >> 3][r & 7] = f2bf(p);
-            }
-        l_run = l_run * alpha + psum;
-        if (__any(alpha != 1.0f)) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-        }
-        // ---- O^T += V^T . P^T
-        const int gi = lane >> 4, li = lane & 15;
-        const int tr_q = li >> 2, tr_p = li & 3;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int ch = 4 * dt + 2 * (gi & 1) + (tr_p >> 1);   // 16-B chunk of columns 32dt+16(gi&1)+4p
+            // ---- causal mask, online softmax (query on the lane).  Scores stay unscaled: the scale is
+            // folded into the exponent, p = exp2(s * scale*log2e - m), one FMA per element.
+            const bool need_mask = kt * 64 + 63 > wave_first_row + shift;
+            const int vis = qrow + shift;          // last visible key of this lane's query
+            float mx = -INFINITY;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int r0 = 32 * t2 + 16 * s + 4 * (gi >> 1) + tr_q;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (LDS_AS bf16x4*)(sm_v + v_off(r0, ch) + 8 * (tr_p & 1)));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                        (LDS_AS bf16x4*)(sm_v + v_off(r0 + 8, ch) + 8 * (tr_p & 1)));
-                    const bf16x8 vfrag = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb[t2][s], o[dt], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) {
+                    if (need_mask) {
+                        const int key = kt * 64 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        st[t2][r] = key > vis ? -INFINITY : st[t2][r];
+                    }
+                    mx = fmaxf(mx, st[t2][r]);
                 }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;
+            // The running max only moves when some query's max grew by more than 2^RESCALE_LOG2: below
+            // that, p <= 2^RESCALE_LOG2 is still exact enough in bf16/fp32 and the O rescale is skipped.
+            constexpr float RESCALE_LOG2 = 6.0f;
+            float alpha = 1.0f;
+            if (__any(mx > m_run + RESCALE_LOG2)) {
+                const float m_new = fmaxf(m_run, mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+                m_run = m_new;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
+            const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
+            float psum = 0.f;
+            bf16x8 pb[2][2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t2][r], scale_log2, neg_m));
+                    psum += p;
+                    pb[t2][r >> 3][r & 7] = f2bf(p);
+                }
+            l_run = l_run * alpha + psum;
+            // ---- O^T += V^T . P^T
+            const int gi = lane >> 4, li = lane & 15;
+            const int tr_q = li >> 2, tr_p = li & 3;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int ch = 4 * dt + 2 * (gi & 1) + (tr_p >> 1);   // 16-B chunk of columns 32dt+16(gi&1)+4p
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int sft = 0; sft < 2; ++sft) {
+                        const int r0 = 32 * t2 + 16 * sft + 4 * (gi >> 1) + tr_q;
+                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (LDS_AS bf16x4*)(sm_v + v_off(r0, ch) + 8 * (tr_p & 1)));
+                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                            (LDS_AS bf16x4*)(sm_v + v_off(r0 + 8, ch) + 8 * (tr_p & 1)));
+                        const bf16x8 vfrag = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb[t2][sft], o[dt], 0, 0, 0);
+                    }
+            }
         }
     }
 
-    // ---- normalise and store: lane (q, hh) holds O[q][32dt + 8(r>>2) + 4hh + (r&3)]
+    // ---- lane (q, hh) holds O[q][32dt + 8(r>>2) + 4hh + (r&3)]
     l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    if (qrow_raw < lq) {
+    if (qrow_raw >= lq) return;
+    if (num_splits == 1) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         bf16* op = out + ((int64_t)(q_beg + qrow_raw) * hq + h) * 128 + 4 * hh;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
@@ -197,43 +203,107 @@ __global__ __launch_bounds__(G * RB * 64) void attn_varlen_kernel(
                 for (int e = 0; e < 4; ++e) v[e] = f2bf(o[dt][r4 * 4 + e] * inv);
                 *reinterpret_cast<bf16x4*>(op + 32 * dt + 8 * r4) = v;
             }
+    } else {
+        // unnormalised partial + (max, sum) for the combine kernel; a range with no visible key leaves sum 0
+        const int64_t slab = ((int64_t)(q_beg + qrow_raw) * hq + h) * num_splits + split;
+        if (l_run > 0.f) {
+            float* op = ws_acc + slab * 128 + 4 * hh;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = o[dt][r4 * 4 + e];
+                    *reinterpret_cast<f32x4*>(op + 32 * dt + 8 * r4) = v;
+                }
+        }
+        if (hh == 0) {
+            ws_ml[slab * 2] = m_run;
+            ws_ml[slab * 2 + 1] = l_run;
+        }
     }
 }
 
+namespace {
+struct VarlenArgs {
+    const bf16 *q, *k, *v;
+    int64_t qs, kvs;
+    const int32_t *cu_q, *cu_k, *tables;
+    int64_t ts;
+    int hkv;
+    float sl2;
+    bf16* out;
+    int num_splits, tiles_per_split;
+    float *ws_acc, *ws_ml;
+};
+
 template <int G, int RB>
-static void launch_varlen(bool paged, dim3 grid, hipStream_t st, const bf16* q, int64_t qs, const bf16* k, const bf16* v,
-                          int64_t kvs, const int32_t* cu_q, const int32_t* cu_k, const int32_t* tables, int64_t ts, int hkv,
-                          float sl2, bf16* out) {
+void launch_varlen(bool paged, dim3 grid, hipStream_t st, const VarlenArgs& a) {
+    constexpr int smem = 2 * 2 * 64 * 256;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+    }
     if (paged)
-        attn_varlen_kernel<G, RB, true><<<grid, G * RB * 64, 0, st>>>(q, qs, k, v, kvs, cu_q, cu_k, tables, ts, hkv, sl2, out);
+        attn_varlen_kernel<G, RB, true><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts, a.hkv,
+                                                                        a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
     else
-        attn_varlen_kernel<G, RB, false><<<grid, G * RB * 64, 0, st>>>(q, qs, k, v, kvs, cu_q, cu_k, tables, ts, hkv, sl2, out);
+        attn_varlen_kernel<G, RB, false><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts, a.hkv,
+                                                                         a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
+}
+
+int rows_per_block(int g) { return g == 1 ? 128 : g == 2 ? 64 : 32; }
+}  // namespace
+
+extern "C" int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
+                                                  int64_t max_seqlen_k) {
+    // Aim for ~512 workgroups (2 per CU); never less than 4 key tiles (256 keys) per range.
+    if (num_kv_heads <= 0 || num_q_heads % num_kv_heads) return 1;
+    const int bq = rows_per_block((int)(num_q_heads / num_kv_heads));
+    const int64_t blocks = (total_q / bq + batch) * num_kv_heads;
+    int64_t s = nvh_cdiv(512, blocks > 0 ? blocks : 1);
+    const int64_t cap = nvh_cdiv(max_seqlen_k, 64) / 4;
+    if (s > cap) s = cap;
+    if (s > 32) s = 32;
+    return (int32_t)(s < 1 ? 1 : s);
+}
+
+extern "C" int64_t nvh_attn_varlen_workspace_bytes(int64_t total_q, int64_t num_q_heads, int64_t head_dim, int32_t num_splits) {
+    if (num_splits <= 1) return 0;
+    return total_q * num_q_heads * num_splits * (head_dim + 2) * (int64_t)sizeof(float);
 }
 
 extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const void* k, const void* v,
                                    int64_t kv_token_stride, const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                                    const int32_t* block_tables, int64_t table_stride, int64_t batch, int64_t max_seqlen_q,
-                                   int64_t total_q, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                                   float softmax_scale, void* out, nvh_stream_t stream) {
+                                   int64_t max_seqlen_k, int64_t total_q, int64_t num_q_heads, int64_t num_kv_heads,
+                                   int64_t head_dim, float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                                   nvh_stream_t stream) {
     NVH_REQUIRE(q && k && v && cu_seqlens_q && cu_seqlens_k && out, NVH_EINVAL, "nvh_attn_varlen: null pointer");
     NVH_REQUIRE(head_dim == 128, NVH_ENOSYS, "nvh_attn_varlen: head_dim %ld unsupported (128 only)", (long)head_dim);
     NVH_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, NVH_EINVAL, "nvh_attn_varlen: Hq %% Hkv != 0");
     NVH_REQUIRE(q_token_stride % 8 == 0 && kv_token_stride % 8 == 0 && nvh_aligned16(q) && nvh_aligned16(k) && nvh_aligned16(v) && ((uintptr_t)out & 7) == 0,
                 NVH_EINVAL, "nvh_attn_varlen: 16-byte alignment required");
-    NVH_REQUIRE(batch <= 65535 && num_kv_heads <= 65535, NVH_EINVAL, "nvh_attn_varlen: batch/heads exceed grid limits");
-    (void)total_q;
-    if (batch == 0 || max_seqlen_q == 0) return NVH_OK;
+    NVH_REQUIRE(num_splits >= 1 && num_splits <= 64 && (num_splits == 1 || (workspace && nvh_aligned16(workspace))), NVH_EINVAL,
+                "nvh_attn_varlen: num_splits %d needs a 16-byte aligned workspace", num_splits);
+    NVH_REQUIRE(batch * num_splits <= 65535 && num_kv_heads <= 65535, NVH_EINVAL, "nvh_attn_varlen: batch/heads exceed grid limits");
+    if (batch == 0 || max_seqlen_q == 0 || total_q == 0) return NVH_OK;
     const int g = (int)(num_q_heads / num_kv_heads);
     const bool paged = block_tables != nullptr;
-    const float sl2 = softmax_scale * LOG2E;
     hipStream_t st = (hipStream_t)stream;
-    const bf16 *qp = (const bf16*)q, *kp = (const bf16*)k, *vp = (const bf16*)v;
-    bf16* op = (bf16*)out;
-#define LAUNCH_VL(GG, RBB)                                                                                          \
-    do {                                                                                                            \
-        dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)batch);             \
-        launch_varlen<GG, RBB>(paged, grid, st, qp, q_token_stride, kp, vp, kv_token_stride, cu_seqlens_q,          \
-                               cu_seqlens_k, block_tables, table_stride, (int)num_kv_heads, sl2, op);               \
+    float* ws_acc = (float*)workspace;
+    float* ws_ml = ws_acc ? ws_acc + total_q * num_q_heads * num_splits * 128 : nullptr;
+    const int tiles = (int)nvh_cdiv(max_seqlen_k > 0 ? max_seqlen_k : 1, 64);
+    VarlenArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, q_token_stride, kv_token_stride, cu_seqlens_q, cu_seqlens_k,
+                 block_tables, table_stride, (int)num_kv_heads, softmax_scale * LOG2E, (bf16*)out, num_splits,
+                 (int)nvh_cdiv(tiles, num_splits), ws_acc, ws_ml};
+#define LAUNCH_VL(GG, RBB)                                                                                                  \
+    do {                                                                                                                    \
+        dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));      \
+        launch_varlen<GG, RBB>(paged, grid, st, a);                                                                         \
     } while (0)
     switch (g) {
         case 1: LAUNCH_VL(1, 4); break;
@@ -247,5 +317,8 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
     }
 #undef LAUNCH_VL
     NVH_CHECK_LAUNCH("attn_varlen");
+    if (num_splits > 1) {
+        return nvh_launch_attn_combine(ws_acc, ws_ml, out, total_q * num_q_heads, num_splits, st);   // same records as decode
+    }
     return NVH_OK;
 }

@@ -29,10 +29,24 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(
             float xv[8];
             if constexpr (PARTIALS) {
                 float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int p = 0; p < num_partials; ++p) {
-                    const float* src = partials + ((int64_t)p * rows + r) * dim + c * 8;
-                    f32x4 a = *reinterpret_cast<const f32x4*>(src);
-                    f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+                const float* src0 = partials + r * (int64_t)dim + c * 8;
+                const int64_t slab = rows * (int64_t)dim;
+                int p = 0;
+                for (; p + 4 <= num_partials; p += 4) {          // 8 independent loads in flight
+                    f32x4 a[4], b[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a[u] = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab);
+                        b[u] = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { acc[j] += a[u][j]; acc[4 + j] += b[u][j]; }
+                }
+                for (; p < num_partials; ++p) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + p * slab);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + p * slab + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
                 }

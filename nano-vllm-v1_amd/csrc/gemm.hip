@@ -20,6 +20,7 @@
 // The tile shape is picked per call so that the grid covers the 256 CUs (small tiles for narrow
 // outputs, BM = 16/32/64 for decode batches); split-K (gridDim.z) adds workgroups for narrow-N
 // projections, writing fp32 slabs that the consumer kernel sums.
+#include <stdlib.h>
 #include "common.h"
 
 #define BK 64
@@ -42,7 +43,7 @@ __device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
     }
 }
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split) {
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     // source row pointers of this wave's PW pieces (k offset added per tile)
     const bf16* src_row[PW];
     int lds_off[PW];
+    bool piece_is_w[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
         int p = wave + i * 4;
@@ -82,13 +84,19 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
         if (is_b) src_row[i] = x + (int64_t)min(m0 + r, M - 1) * x_stride + chunk * 8;
         else src_row[i] = w + (int64_t)min(n0 + r, N - 1) * K + chunk * 8;
         lds_off[i] = (is_b ? A_BYTES : 0) + grp * 1024;
+        piece_is_w[i] = !is_b;
     }
     auto stage = [&](int t) {
         const int k0 = kbeg + t * BK;
         char* base = smem + (t % STAGES) * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < PW; ++i)
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[i] + k0), (LDS_AS void*)(base + lds_off[i]), 16, 0, 0);
+        for (int i = 0; i < PW; ++i) {
+            // weights that only this workgroup row reads (one M tile: decode) are streamed non-temporally
+            if (NT_W && piece_is_w[i])
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[i] + k0), (LDS_AS void*)(base + lds_off[i]), 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[i] + k0), (LDS_AS void*)(base + lds_off[i]), 16, 0, 0);
+        }
     };
 
     f32x4 acc[TN][TM];
@@ -167,12 +175,12 @@ struct GemmArgs {
     hipStream_t st;
 };
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
-void launch_gemm(const GemmArgs& a) {
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W>
+void launch_gemm_nt(const GemmArgs& a) {
     constexpr int smem = STAGES * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool configured = false;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W>;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
@@ -181,6 +189,13 @@ void launch_gemm(const GemmArgs& a) {
     const int k_per_split = (int)nvh_cdiv(ktiles, a.split_k) * BK;
     dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
     kern<<<grid, 256, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split);
+}
+
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
+void launch_gemm(const GemmArgs& a) {
+    static const bool no_nt = getenv("NVH_GEMM_NO_NT") != nullptr;   // A/B switch for tuning
+    if (a.M <= BM && !no_nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true>(a);
+    else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false>(a);
 }
 
 // Tile choice: the largest tile whose grid (x split_k) still gives every CU a workgroup.

@@ -4,10 +4,12 @@
 #include "common.h"
 
 namespace {
+constexpr int32_t kMaxVarlenSplits = 8;
 struct Workspace {
     bf16 *residual, *x, *y, *qkv, *attn, *gate_up, *act;
     float* slabs;
     void* decode_ws;
+    void* varlen_ws;
     int64_t total;
 };
 
@@ -15,7 +17,7 @@ inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
 
 int32_t split_for(int64_t m, int64_t n, int64_t k) { return nvh_gemm_suggest_split_k(m, n, k); }
 
-Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_splits, char* base) {
+Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_splits, int32_t varlen_splits, char* base) {
     const int64_t h = md->hidden, d = md->head_dim;
     const int64_t qsz = (int64_t)md->num_q_heads * d, kvsz = (int64_t)md->num_kv_heads * d;
     Workspace w;
@@ -32,6 +34,7 @@ Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_
     const int64_t smax = so > sd ? so : sd;
     w.slabs = (float*)take(smax > 1 ? smax * t * h * 4 : 0);
     w.decode_ws = take(nvh_attn_decode_workspace_bytes(b, md->num_q_heads, d, decode_splits));
+    w.varlen_ws = take(nvh_attn_varlen_workspace_bytes(t, md->num_q_heads, d, varlen_splits));
     w.total = off;
     return w;
 }
@@ -40,7 +43,8 @@ Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_
 extern "C" int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_tokens, int64_t batch,
                                              int32_t decode_splits) {
     if (!model || num_tokens < 0) return -1;
-    return carve(model, num_tokens, batch, decode_splits < 1 ? 1 : decode_splits, nullptr).total;
+    // sized for the widest key split the executor lets the var-len path choose
+    return carve(model, num_tokens, batch, decode_splits < 1 ? 1 : decode_splits, kMaxVarlenSplits, nullptr).total;
 }
 
 #define FWD(call)                 \
@@ -57,7 +61,12 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
     if (t == 0) return NVH_OK;
     const int32_t dsplits = st->decode_splits < 1 ? 1 : st->decode_splits;
     NVH_REQUIRE(workspace && nvh_aligned16(workspace), NVH_EINVAL, "nvh_qwen3_forward: workspace missing or misaligned");
-    Workspace w = carve(md, t, b, dsplits, (char*)workspace);
+    int32_t vsplits = 1;
+    if (st->mode != NVH_MODE_DECODE) {
+        vsplits = nvh_attn_varlen_suggest_splits(t, b, md->num_q_heads, md->num_kv_heads, st->max_seqlen_k);
+        if (vsplits > kMaxVarlenSplits) vsplits = kMaxVarlenSplits;
+    }
+    Workspace w = carve(md, t, b, dsplits, kMaxVarlenSplits, (char*)workspace);
     NVH_REQUIRE(w.total <= workspace_bytes, NVH_EINVAL, "nvh_qwen3_forward: workspace too small (%ld < %ld)",
                 (long)workspace_bytes, (long)w.total);
     NVH_REQUIRE(st->mode == NVH_MODE_PACKED || st->block_tables, NVH_EINVAL, "nvh_qwen3_forward: paged modes need block_tables");
@@ -93,10 +102,10 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
                                 d, scale, w.attn, dsplits, w.decode_ws, stream));
         } else if (st->mode == NVH_MODE_PAGED) {
             FWD(nvh_attn_varlen(w.qkv, qkv_n, kc, vc, kvsz, st->cu_seqlens_q, st->cu_seqlens_k, st->block_tables,
-                                st->table_stride, b, st->max_seqlen_q, t, hq, hkv, d, scale, w.attn, stream));
+                                st->table_stride, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
         } else {
             FWD(nvh_attn_varlen(w.qkv, qkv_n, w.qkv + qsz, w.qkv + qsz + kvsz, qkv_n, st->cu_seqlens_q, st->cu_seqlens_k,
-                                nullptr, 0, b, st->max_seqlen_q, t, hq, hkv, d, scale, w.attn, stream));
+                                nullptr, 0, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
         }
         // ---- O projection -> add + norm
         if (so > 1) {

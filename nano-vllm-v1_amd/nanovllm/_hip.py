@@ -31,7 +31,9 @@ SIGNATURES = {
     "nvh_gemm_workspace_bytes": (i64, [i64, i64, i32]),
     "nvh_gemm_suggest_split_k": (i32, [i64, i64, i64]),
     "nvh_splitk_reduce": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
-    "nvh_attn_varlen": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, f32, vp, vp]),
+    "nvh_attn_varlen": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
+    "nvh_attn_varlen_workspace_bytes": (i64, [i64, i64, i64, i32]),
+    "nvh_attn_varlen_suggest_splits": (i32, [i64, i64, i64, i64, i64]),
     "nvh_attn_decode": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
     "nvh_attn_decode_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_decode_suggest_splits": (i32, [i64, i64, i64]),

@@ -49,8 +49,9 @@ class Attention(nn.Module):
                 return ops.attn_decode(q, self.k_cache, self.v_cache, ctx.context_lens, ctx.block_tables, self.scale,
                                        0, ctx.max_seqlen_k)
             return ops.attn_varlen(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q, ctx.cu_seqlens_k,
-                                   ctx.max_seqlen_q, self.scale, ctx.block_tables)
-        return ops.attn_varlen(q, k, v, ctx.cu_seqlens_q, ctx.cu_seqlens_k, ctx.max_seqlen_q, self.scale)
+                                   ctx.max_seqlen_q, self.scale, ctx.block_tables, ctx.max_seqlen_k or None)
+        return ops.attn_varlen(q, k, v, ctx.cu_seqlens_q, ctx.cu_seqlens_k, ctx.max_seqlen_q, self.scale,
+                               None, ctx.max_seqlen_k or None)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         ctx = get_context()

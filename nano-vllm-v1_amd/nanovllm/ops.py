@@ -175,7 +175,8 @@ def splitk_reduce(partials: torch.Tensor, bias: torch.Tensor | None = None) -> t
 
 
 # ---------------------------------------------------------------- attention
-def attn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, scale: float, block_tables=None) -> torch.Tensor:
+def attn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, scale: float, block_tables=None,
+                max_seqlen_k: int | None = None, num_splits: int = 0) -> torch.Tensor:
     """q [T,Hq,128]; (k, v) packed [Tk,Hkv,128] or page pools [P,256,Hkv,128] with block_tables [B,W] int32."""
     _gpu_bf16(q, k, v)
     t, hq, d = q.shape
@@ -190,9 +191,19 @@ def attn_varlen(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q: int, scale: f
         assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
         kv_stride, tbl, tbl_stride = hkv * d, block_tables.data_ptr(), block_tables.stride(0)
     out = torch.empty(t, hq, d, dtype=BF16, device=q.device)
+    batch = cu_seqlens_q.numel() - 1
+    if max_seqlen_k is None:        # upper bound: every key of the pool / packed buffer
+        max_seqlen_k = block_tables.shape[1] * KV_PAGE if block_tables is not None else k.shape[0]
+    lib = _hip.lib()
+    if num_splits <= 0:
+        num_splits = lib.nvh_attn_varlen_suggest_splits(t, batch, hq, hkv, max_seqlen_k)
+    ws = 0
+    if num_splits > 1:
+        ws_t = torch.empty(lib.nvh_attn_varlen_workspace_bytes(t, hq, d, num_splits) // 4, dtype=torch.float32, device=q.device)
+        ws = ws_t.data_ptr()
     _hip.call("nvh_attn_varlen", q.data_ptr(), q.stride(0), k.data_ptr(), v.data_ptr(), kv_stride,
-              cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), tbl, tbl_stride, cu_seqlens_q.numel() - 1,
-              max_seqlen_q, t, hq, hkv, d, float(scale), out.data_ptr(), _stream())
+              cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), tbl, tbl_stride, batch,
+              max_seqlen_q, max_seqlen_k, t, hq, hkv, d, float(scale), out.data_ptr(), num_splits, ws, _stream())
     return out
 
 

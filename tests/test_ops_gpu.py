@@ -300,8 +300,11 @@ def test_attn_varlen_paged_vs_oracle(ops, hq, hkv, case):
     q, kc, vc, bt, cu_q, cu_k = _paged_case(50 + case, lens_q, lens_k, hq, hkv)
     scale = 128 ** -0.5
     ref = R.attention_varlen(q, None, None, cu_q, cu_k, scale, kc, vc, bt)
-    got = ops.attn_varlen(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(lens_q), scale, dev(bt))
-    assert_close(got, ref, 1.5e-2, 2e-2)
+    # key-range splits: heuristic (0), none (1), and counts that leave some ranges empty for short sequences
+    for splits in (0, 1, 3, 8):
+        got = ops.attn_varlen(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(lens_q), scale, dev(bt),
+                              max_seqlen_k=max(lens_k), num_splits=splits)
+        assert_close(got, ref, 1.5e-2, 2e-2)
 
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1)])

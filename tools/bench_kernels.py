@@ -36,16 +36,19 @@ def timeit(fn, iters=50, warmup=5):
     return best / iters * 1e3   # us
 
 
-def gemm(shapes, copies=8):
+def gemm(shapes):
+    """Weights rotate through > 512 MB of copies, so every launch streams them from HBM (cold
+    Infinity Cache), as consecutive layers of a model do."""
     print(f"{'M':>6} {'N':>7} {'K':>6} {'split':>5} {'us':>9} {'TFLOP/s':>9} {'W GB/s':>9}")
     for m, n, k in shapes:
-        xs = [torch.randn(m, k, device="cuda").to(BF) for _ in range(copies)]
+        copies = max(2, min(128, (600 << 20) // (n * k * 2) + 1))
+        xs = [torch.randn(m, k, device="cuda").to(BF) for _ in range(min(copies, 8))]
         ws = [(torch.randn(n, k, device="cuda") * 0.05).to(BF) for _ in range(copies)]
         for split in (1, ops.suggest_split_k(m, n, k)):
             if split == 1:
-                us = timeit(lambda i: ops.linear(xs[i % copies], ws[i % copies]))
+                us = timeit(lambda i: ops.linear(xs[i % len(xs)], ws[i % copies]), iters=max(50, copies))
             else:
-                us = timeit(lambda i: ops.linear_splitk(xs[i % copies], ws[i % copies], split))
+                us = timeit(lambda i: ops.linear_splitk(xs[i % len(xs)], ws[i % copies], split), iters=max(50, copies))
             print(f"{m:6d} {n:7d} {k:6d} {split:5d} {us:9.2f} {2 * m * n * k / us / 1e6:9.1f} {2 * n * k / us / 1e3:9.1f}")
             if split == 1 and ops.suggest_split_k(m, n, k) == 1:
                 break
@@ -62,9 +65,10 @@ def attn_prefill(cases, hq=16, hkv=8):
         bt = torch.arange(pages, dtype=torch.int32, device="cuda").view(1, -1)
         cu_q = torch.tensor([0, lq], dtype=torch.int32, device="cuda")
         cu_k = torch.tensor([0, lk], dtype=torch.int32, device="cuda")
-        us = timeit(lambda i: ops.attn_varlen(q, kc, vc, cu_q, cu_k, lq, d ** -0.5, bt), iters=20)
         vis = lq * (lk - lq) + lq * (lq + 1) // 2
-        print(f"{lq:6d} {lk:6d} {us:9.2f} {4 * hq * d * vis / us / 1e6:9.1f}")
+        for sp in (0, 1, 2, 4, 8):
+            us = timeit(lambda i: ops.attn_varlen(q, kc, vc, cu_q, cu_k, lq, d ** -0.5, bt, max_seqlen_k=lk, num_splits=sp), iters=20)
+            print(f"{lq:6d} {lk:6d} splits={sp} {us:9.2f} {4 * hq * d * vis / us / 1e6:9.1f}")
 
 
 def attn_decode(cases, hq=16, hkv=8, layers=8):
@@ -95,3 +99,23 @@ if __name__ == "__main__":
         attn_prefill([(1024, 1024), (1024, 2048), (1024, 4096), (1024, 8192), (128, 128)])
     if "decode" in a.what:
         attn_decode([(256, 1024), (32, 1024), (1, 1024), (1, 8192), (64, 4096)])
+
+
+def attn_decode_layout_probe():
+    """Same bytes and workgroup count as B=256/Hkv=8, but every workgroup's K/V rows are contiguous
+    (Hkv=1): tells how much the 2-KiB token stride of the [page,256,Hkv,D] layout costs."""
+    d = 128
+    for (b, hq, hkv, ctx) in ((256, 16, 8, 1024), (2048, 2, 1, 1024)):
+        layers = 8
+        pages = b * ((ctx + 255) // 256)
+        kcs = [torch.randn(pages, 256, hkv, d, device="cuda").to(BF) for _ in range(layers)]
+        vcs = [torch.randn(pages, 256, hkv, d, device="cuda").to(BF) for _ in range(layers)]
+        q = torch.randn(b, hq, d, device="cuda").to(BF)
+        bt = torch.arange(pages, dtype=torch.int32, device="cuda").view(b, -1)
+        cl = torch.full((b,), ctx, dtype=torch.int32, device="cuda")
+        us = timeit(lambda i: ops.attn_decode(q, kcs[i % layers], vcs[i % layers], cl, bt, d ** -0.5, num_splits=1), iters=40)
+        print(f"B={b} Hq={hq} Hkv={hkv} ctx={ctx}: {us:9.2f} us {b * ctx * hkv * d * 4 / us / 1e3:9.1f} GB/s")
+
+
+if __name__ == "__main__" and "layout" in sys.argv:
+    attn_decode_layout_probe()

@@ -4,7 +4,7 @@ usage: step_breakdown.py <kernel_trace.csv>"""
 import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'sample_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if ('sample_final_kernel' in r['Kernel_Name'] or 'sample_kernel' in r['Kernel_Name'])]
 a, b = idx[-2], idx[-1]
 step = rows[a + 1:b + 1]
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
