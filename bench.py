@@ -169,9 +169,19 @@ def kernel_roofline(runner, seqs, iters):
     avg_ms = total_ms / n
     bytes_per_launch = int(fb["context_lens"].sum()) * hkv * d * 2 * 2      # K and V rows, bf16
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE, own rocprofv3 run,
+    # doubled as gfx950 requires), scaled from that run's context length to this one's.
+    traffic, traffic_note = None, None
+    pmc = ROOT / "profiles" / "r01_attn_decode_traffic.json"
+    if pmc.exists() and tp == 1 and b == 256:
+        rec = json.loads(pmc.read_text())
+        ratio = rec["traffic_bytes_per_launch"] / rec["algorithmic_bytes_per_launch_at_ctx1027"]
+        traffic = int(bytes_per_launch * ratio)
+        traffic_note = f"profiles/{pmc.name}: measured/algorithmic = {ratio:.4f}"
     return dict(bound="hbm", kernel="attn_decode_kernel" + ("+combine" if splits > 1 else ""), achieved=round(achieved, 1),
-                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
-                avg_launch_us=round(avg_ms * 1e3, 2), bytes_per_launch=bytes_per_launch, launches_timed=n)
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                traffic_source=traffic_note, avg_launch_us=round(avg_ms * 1e3, 2), bytes_per_launch=bytes_per_launch,
+                launches_timed=n)
 
 
 def cpu_baseline(hf, budget_s=12.0):
