@@ -118,6 +118,15 @@ int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K);
 int32_t nvh_splitk_reduce(const float* partials, int64_t num_partials, const void* bias,
                           void* y, int64_t y_row_stride, int64_t M, int64_t N, nvh_stream_t stream);
 
+/* gate_up GEMM (layers/linear.py:198 via models/qwen3.py:270) fused with the SwiGLU gate
+ * (layers/activation.py:36-58): y[M, N/2] = silu(x Wg^T) * (x Wu^T), same rounding points as
+ * nvh_gemm_bf16_nt followed by nvh_silu_mul.  `w_interleaved` is the merged [gate | up] weight
+ * ([N = 2I, K]) re-ordered by nvh_interleave_gate_up: blocks of 16 gate rows followed by the 16 up
+ * rows of the same outputs, so both land in one lane's accumulators. */
+int32_t nvh_gemm_swiglu_bf16_nt(const void* x, int64_t x_row_stride, const void* w_interleaved, void* y,
+                                int64_t y_row_stride, int64_t M, int64_t N, int64_t K, nvh_stream_t stream);
+int32_t nvh_interleave_gate_up(const void* w, void* w_interleaved, int64_t inter, int64_t K, nvh_stream_t stream);
+
 /* ---- K2: paged / packed var-len causal GQA attention (prefill, chunked prefill, mixed).
  * layers/attention.py:236-248 (flash_attn_varlen_func).  q [T,Hq,D] packed by
  * cu_seqlens_q[B+1].  block_tables == NULL: k,v are the packed new tokens [Tk,Hkv,D]
@@ -193,7 +202,8 @@ typedef struct {
     const void* const* o_w;            /* [hidden, Hq*D] */
     const void* const* q_norm;         /* [D] */
     const void* const* k_norm;         /* [D] */
-    const void* const* gate_up_w;      /* [2*inter, hidden] */
+    const void* const* gate_up_w;      /* [2*inter, hidden], rows [gate | up] */
+    const void* const* gate_up_inter;  /* same rows in nvh_interleave_gate_up order, or NULL: unfused SiLU*mul */
     const void* const* down_w;         /* [hidden, inter] */
     const void* const* input_norm;     /* [hidden] */
     const void* const* post_norm;      /* [hidden] */

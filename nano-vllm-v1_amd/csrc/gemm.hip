@@ -43,7 +43,7 @@ __device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
     }
 }
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W>
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split) {
@@ -139,6 +139,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     }
 
     // epilogue: lane holds n = n_base + fq*4 .. +3 of row m = m_base + fr
+    if constexpr (SWIGLU) {
+        // W rows are interleaved in blocks of 16: [gate 16b..16b+15 | up 16b..16b+15], so tile i (even) holds
+        // gate and tile i+1 the matching up columns in the same lanes.  y[m][16b + ..] = silu(gate) * up with the
+        // rounding points of the separate kernels: GEMM output -> bf16, silu -> bf16, product -> bf16.
+        static_assert(TN % 2 == 0, "SwiGLU epilogue pairs 16-row tiles");
+#pragma unroll
+        for (int i = 0; i < TN; i += 2) {
+            const int n = n0 + wn * WN + i * 16;                 // first interleaved row of the gate block
+            if (n >= N) continue;
+            const int col = (n >> 5) * 16 + fq * 4;              // output column
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = m0 + wm * WM + j * 16 + fr;
+                if (m >= M) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gv = bf2f(f2bf(acc[i][j][e]));
+                    const float uv = bf2f(f2bf(acc[i + 1][j][e]));
+                    const float sl = gv / (1.0f + expf(-gv));
+                    o[e] = f2bf(bf2f(f2bf(sl)) * uv);
+                }
+                *reinterpret_cast<bf16x4*>(y + (int64_t)m * y_stride + col) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
         const int n = n0 + wn * WN + i * 16 + fq * 4;
@@ -173,14 +200,15 @@ struct GemmArgs {
     int64_t xs, ys;
     int M, N, K, split_k;
     hipStream_t st;
+    bool swiglu;
 };
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W>
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU>
 void launch_gemm_nt(const GemmArgs& a) {
     constexpr int smem = STAGES * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool configured = false;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU>;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
@@ -194,8 +222,14 @@ void launch_gemm_nt(const GemmArgs& a) {
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
 void launch_gemm(const GemmArgs& a) {
     static const bool no_nt = getenv("NVH_GEMM_NO_NT") != nullptr;   // A/B switch for tuning
-    if (a.M <= BM && !no_nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true>(a);
-    else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false>(a);
+    const bool nt = a.M <= BM && !no_nt;
+    if (a.swiglu) {
+        if (nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true, true>(a);
+        else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, true>(a);
+    } else {
+        if (nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true, false>(a);
+        else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, false>(a);
+    }
 }
 
 // Tile choice: the largest tile whose grid (x split_k) still gives every CU a workgroup.
@@ -212,6 +246,7 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
 int tile_bm(Tile t) { return t == T16x128 ? 16 : t == T32x128 ? 32 : (t == T64x128 || t == T64x64) ? 64 : 128; }
 int tile_bn(Tile t) { return (t == T64x64 || t == T128x64) ? 64 : 128; }
 }  // namespace
+static int32_t dispatch_gemm(const GemmArgs& a);
 
 extern "C" int64_t nvh_gemm_workspace_bytes(int64_t M, int64_t N, int32_t split_k) {
     return split_k > 1 ? (int64_t)split_k * M * N * (int64_t)sizeof(float) : 0;
@@ -249,8 +284,12 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
     }
     if (M == 0) return NVH_OK;
     GemmArgs a{(const bf16*)x, (const bf16*)w, (const bf16*)bias, (bf16*)y, split_k > 1 ? workspace : nullptr,
-               x_row_stride, y_row_stride, (int)M, (int)N, (int)K, split_k, (hipStream_t)stream};
-    switch (pick_tile(M, N, split_k)) {
+               x_row_stride, y_row_stride, (int)M, (int)N, (int)K, split_k, (hipStream_t)stream, false};
+    return dispatch_gemm(a);
+}
+
+static int32_t dispatch_gemm(const GemmArgs& a) {
+    switch (pick_tile(a.M, a.N, a.split_k)) {
         case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;
         case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
@@ -291,5 +330,39 @@ extern "C" int32_t nvh_splitk_reduce(const float* partials, int64_t num_partials
     splitk_reduce_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(partials, (int)num_partials, (const bf16*)bias, (bf16*)y,
                                                                 y_row_stride, M, (int)N);
     NVH_CHECK_LAUNCH("splitk_reduce");
+    return NVH_OK;
+}
+
+// y[M, N/2] = silu(x W_gate^T) * (x W_up^T) in one kernel.  `w` holds the N = 2I rows of the merged
+// gate/up weight INTERLEAVED in blocks of 16 (rows 32b..32b+15 = gate 16b.., rows 32b+16..32b+31 = up 16b..),
+// see nvh_interleave_gate_up.  Same arithmetic and rounding points as nvh_gemm_bf16_nt + nvh_silu_mul.
+extern "C" int32_t nvh_gemm_swiglu_bf16_nt(const void* x, int64_t x_row_stride, const void* w, void* y,
+                                           int64_t y_row_stride, int64_t M, int64_t N, int64_t K, nvh_stream_t stream) {
+    NVH_REQUIRE(x && w && y, NVH_EINVAL, "nvh_gemm_swiglu_bf16_nt: null pointer");
+    NVH_REQUIRE(K > 0 && K % BK == 0 && N > 0 && N % 32 == 0, NVH_EINVAL, "nvh_gemm_swiglu_bf16_nt: K %% 64 and N %% 32 required (K=%ld N=%ld)", (long)K, (long)N);
+    NVH_REQUIRE(M >= 0 && M < (1 << 30) && N < (1 << 30), NVH_EINVAL, "nvh_gemm_swiglu_bf16_nt: M/N out of range");
+    NVH_REQUIRE(x_row_stride % 8 == 0 && y_row_stride % 4 == 0 && nvh_aligned16(x) && nvh_aligned16(w) && ((uintptr_t)y & 7) == 0,
+                NVH_EINVAL, "nvh_gemm_swiglu_bf16_nt: alignment");
+    if (M == 0) return NVH_OK;
+    GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, (bf16*)y, nullptr, x_row_stride, y_row_stride, (int)M, (int)N, (int)K, 1,
+               (hipStream_t)stream, true};
+    return dispatch_gemm(a);
+}
+
+// dst rows <- src rows of a merged [gate (I rows) | up (I rows)] weight in the interleaved order above.
+__global__ __launch_bounds__(256) void interleave_gate_up_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int inter, int k) {
+    const int r = blockIdx.x;                       // destination row
+    const int blk = r >> 5, j = r & 31;
+    const int64_t srow = j < 16 ? (int64_t)blk * 16 + j : (int64_t)inter + blk * 16 + (j - 16);
+    for (int c = threadIdx.x; c < (k >> 3); c += 256)
+        *reinterpret_cast<bf16x8*>(dst + (int64_t)r * k + c * 8) = *reinterpret_cast<const bf16x8*>(src + srow * k + c * 8);
+}
+
+extern "C" int32_t nvh_interleave_gate_up(const void* w, void* w_interleaved, int64_t inter, int64_t K, nvh_stream_t stream) {
+    NVH_REQUIRE(w && w_interleaved && w != w_interleaved, NVH_EINVAL, "nvh_interleave_gate_up: null or aliased pointers");
+    NVH_REQUIRE(inter > 0 && inter % 16 == 0 && K % 8 == 0 && nvh_aligned16(w) && nvh_aligned16(w_interleaved), NVH_EINVAL,
+                "nvh_interleave_gate_up: inter %% 16, K %% 8 and 16-byte alignment required");
+    interleave_gate_up_kernel<<<(unsigned)(2 * inter), 256, 0, (hipStream_t)stream>>>((const bf16*)w, (bf16*)w_interleaved, (int)inter, (int)K);
+    NVH_CHECK_LAUNCH("interleave_gate_up");
     return NVH_OK;
 }

@@ -116,8 +116,12 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
             FWD(nvh_add_rmsnorm(w.y, w.residual, md->post_norm[l], w.x, t, h, md->eps, nullptr, 0, stream));
         }
         // ---- MLP
-        FWD(nvh_gemm_bf16_nt(w.x, h, md->gate_up_w[l], nullptr, w.gate_up, 2 * md->inter, t, 2 * md->inter, h, 1, nullptr, stream));
-        FWD(nvh_silu_mul(w.gate_up, w.act, t, md->inter, stream));
+        if (md->gate_up_inter && md->gate_up_inter[l]) {
+            FWD(nvh_gemm_swiglu_bf16_nt(w.x, h, md->gate_up_inter[l], w.act, md->inter, t, 2 * md->inter, h, stream));
+        } else {
+            FWD(nvh_gemm_bf16_nt(w.x, h, md->gate_up_w[l], nullptr, w.gate_up, 2 * md->inter, t, 2 * md->inter, h, 1, nullptr, stream));
+            FWD(nvh_silu_mul(w.gate_up, w.act, t, md->inter, stream));
+        }
         if (sd > 1) {
             FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, nullptr, h, t, h, md->inter, sd, w.slabs, stream));
             pending_slabs = true;

@@ -187,6 +187,14 @@ class ModelRunner:
                 self.shm = SharedMemory(name=SHM_NAME)
                 self.loop()
 
+    def load_weights(self, named_tensors) -> int:
+        """(Re)load parameters from (name, tensor) pairs in checkpoint naming and refresh everything derived
+        from them (the native executor's pointer table and its interleaved gate/up copies)."""
+        n = load_tensors(self.model, named_tensors)
+        if self.native is not None:
+            self.native.rebuild()
+        return n
+
     # -------------------------------------------------------------- control plane (tp > 1)
     def exit(self):
         if self.shm is not None:

@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from . import _hip
+from . import _hip, ops
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 PP = C.POINTER(vp)
@@ -22,7 +22,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("num_q_heads", i32), ("num_kv_heads", i32), ("head_dim", i32),
                 ("inter", i32), ("vocab_rows", i32), ("reserved", i32), ("eps", f32), ("reserved2", i32),
                 ("max_position", i64), ("embed", vp), ("final_norm", vp), ("lm_head", vp), ("cos_sin", vp),
-                ("qkv_w", PP), ("o_w", PP), ("q_norm", PP), ("k_norm", PP), ("gate_up_w", PP), ("down_w", PP),
+                ("qkv_w", PP), ("o_w", PP), ("q_norm", PP), ("k_norm", PP), ("gate_up_w", PP), ("gate_up_inter", PP), ("down_w", PP),
                 ("input_norm", PP), ("post_norm", PP), ("k_cache", PP), ("v_cache", PP)]
 
 
@@ -37,9 +37,10 @@ def _ptr(t):
 
 
 class NativeQwen3:
-    def __init__(self, model):
+    def __init__(self, model, fuse_swiglu: bool = True):
         self.lib = _hip.lib()
         self.model = model
+        self.fuse_swiglu = fuse_swiglu
         self.rebuild()
 
     def rebuild(self):
@@ -72,6 +73,15 @@ class NativeQwen3:
         d.q_norm = arr("qn", [l.self_attn.q_norm.weight for l in layers])
         d.k_norm = arr("kn", [l.self_attn.k_norm.weight for l in layers])
         d.gate_up_w = arr("gu", [l.mlp.gate_up_proj.weight for l in layers])
+        # interleaved copies for the fused SwiGLU epilogue (one extra copy of the gate/up weights)
+        if self.fuse_swiglu and layers[0].mlp.gate_up_proj.weight.shape[0] % 32 == 0:
+            # refreshed IN PLACE on later rebuilds: captured graphs keep pointing at these buffers
+            prev = getattr(self, "_inter", None) or [None] * len(layers)
+            self._inter = [ops.interleave_gate_up(l.mlp.gate_up_proj.weight.data, out=p) for l, p in zip(layers, prev)]
+            d.gate_up_inter = arr("gui", self._inter)
+        else:
+            self._inter = None
+            d.gate_up_inter = None
         d.down_w = arr("dn", [l.mlp.down_proj.weight for l in layers])
         d.input_norm = arr("in", [l.input_layernorm.weight for l in layers])
         d.post_norm = arr("pn", [l.post_attention_layernorm.weight for l in layers])

@@ -167,6 +167,32 @@ def linear_splitk(x: torch.Tensor, weight: torch.Tensor, split_k: int) -> torch.
     return ws
 
 
+def interleave_gate_up(weight: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """[gate (I rows) | up (I rows)] -> blocks of 16 gate rows followed by their 16 up rows (for linear_swiglu)."""
+    _gpu_bf16(weight)
+    assert weight.is_contiguous() and weight.shape[0] % 32 == 0
+    if out is None:
+        out = torch.empty_like(weight)
+    assert out.shape == weight.shape and out.is_contiguous() and out.data_ptr() != weight.data_ptr()
+    _hip.call("nvh_interleave_gate_up", weight.data_ptr(), out.data_ptr(), weight.shape[0] // 2, weight.shape[1], _stream())
+    return out
+
+
+def linear_swiglu(x: torch.Tensor, weight_interleaved: torch.Tensor) -> torch.Tensor:
+    """silu(x Wg^T) * (x Wu^T) in one kernel; bit-identical to silu_mul(linear(x, W))."""
+    _gpu_bf16(x, weight_interleaved)
+    k = x.shape[-1]
+    n = weight_interleaved.shape[0]
+    x2 = x.reshape(-1, k)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    m = x2.shape[0]
+    y = torch.empty(m, n // 2, dtype=BF16, device=x.device)
+    _hip.call("nvh_gemm_swiglu_bf16_nt", x2.data_ptr(), x2.stride(0), weight_interleaved.data_ptr(), y.data_ptr(), n // 2,
+              m, n, k, _stream())
+    return y.view(*x.shape[:-1], n // 2)
+
+
 def splitk_reduce(partials: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     s, m, n = partials.shape
     y = torch.empty(m, n, dtype=BF16, device=partials.device)

@@ -40,13 +40,12 @@ def make_runner(enforce_eager, num_blocks=12, native=True, **kw):
     os.environ["NANOVLLM_NATIVE"] = "1" if native else "0"
     from nanovllm.config import Config
     from nanovllm.engine.model_runner import ModelRunner
-    from nanovllm.utils.loader import load_tensors
     cfg = Config(TINY_DIR, max_num_batched_tokens=1024, max_num_seqs=8, max_model_len=2048,
                  enforce_eager=enforce_eager, num_kvcache_blocks=num_blocks, chunked_prefill=True, **kw)
     runner = ModelRunner(cfg, 0, [])
     shape = M.ModelShape(**TINY)
     weights = M.random_weights(shape, seed=0, std=0.05)
-    n = load_tensors(runner.model, hf_named(weights, shape))
+    n = runner.load_weights(hf_named(weights, shape))
     assert n == 1 + 2 * 11 + 1
     assert (runner.native is not None) == native
     return runner, M.RefRunner(shape, weights, num_blocks)

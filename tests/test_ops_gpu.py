@@ -232,6 +232,19 @@ def test_gemm_bias_strided_input_and_splitk(ops):
         assert_gemm(ops.splitk_reduce(slabs, dev(b)), ref)
 
 
+@pytest.mark.parametrize("m,inter,k", [(1, 3072, 1024), (20, 512, 256), (256, 3072, 1024), (1024, 3072, 1024), (70, 96, 192)])
+def test_gemm_swiglu_epilogue_bit_identical_to_separate_kernels(ops, m, inter, k):
+    x, w = rnd(m, k, seed=m + 1), rnd(2 * inter, k, seed=k + 2, scale=0.05)
+    xd, wd = dev(x), dev(w)
+    sep = ops.silu_mul(ops.linear(xd, wd))
+    wi = ops.interleave_gate_up(wd)
+    # interleaved rows: block b = 16 gate rows then the 16 up rows of the same outputs
+    assert torch.equal(wi[:16].cpu(), w[:16]) and torch.equal(wi[16:32].cpu(), w[inter:inter + 16])
+    fused = ops.linear_swiglu(xd, wi)
+    assert_exact(fused, sep.cpu())
+    assert_gemm(fused, R.silu_mul(R.linear(x, w)), max_frac=0.05)
+
+
 def _paged_case(seed, lens_q, lens_k, hq, hkv, num_pages=40):
     """Random q for the new tokens and a cache holding every sequence's lk keys in shuffled pages."""
     g = torch.Generator().manual_seed(seed)
