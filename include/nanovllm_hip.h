@@ -159,6 +159,17 @@ int32_t nvh_attn_decode(const void* q, int64_t q_token_stride,
                         int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
                         float softmax_scale, void* out, int32_t num_splits, void* workspace,
                         nvh_stream_t stream);
+/* Decode step fusion: `qkv` is the raw fused projection output [B, (Hq+2Hkv)*D] of the single new token of
+ * every sequence.  One launch applies the per-head RMSNorm + RoPE to q and k (models/qwen3.py:191-195),
+ * writes the new K/V rows to the cache slot of token context_lens[b]-1 (layers/attention.py:219-220) and
+ * attends (:229-232).  Same bits as nvh_qknorm_rope_store followed by nvh_attn_decode; qkv is left untouched. */
+int32_t nvh_attn_decode_fused_qkv(const void* qkv, int64_t token_stride, const void* q_norm_weight,
+                                  const void* k_norm_weight, float eps, const int64_t* positions,
+                                  const float* cos_sin, void* k_cache, void* v_cache,
+                                  const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                  int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                  float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                                  nvh_stream_t stream);
 int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t head_dim, int32_t num_splits);
 int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int64_t max_context);
 

@@ -13,11 +13,23 @@
 
 #define LOG2E 1.4426950408889634f
 
-template <int G>
+// FUSED: `q` is the raw fused qkv row of the step's single new token per sequence.  The kernel applies the
+// q/k epilogue itself (per-head RMSNorm + RoPE, qknorm_rope_head), uses the new token's K/V straight from
+// registers for its own dot product and writes them to their cache slot (token ctx-1 of the sequence), so
+// the separate norm/rope/store launch disappears from a decode step.
+struct FusedQkv {
+    const bf16* q_norm_w;
+    const bf16* k_norm_w;
+    const int64_t* positions;
+    const float* cos_sin;
+    float eps;
+};
+
+template <int G, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(
-    const bf16* __restrict__ q, int64_t q_stride, const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+    const bf16* __restrict__ q, int64_t q_stride, bf16* __restrict__ kc, bf16* __restrict__ vc,
     const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ tables, int64_t table_stride, int hkv,
-    float scale_log2, bf16* __restrict__ out, float* __restrict__ ws_acc, float* __restrict__ ws_ml) {
+    float scale_log2, bf16* __restrict__ out, float* __restrict__ ws_acc, float* __restrict__ ws_ml, FusedQkv fz) {
     __shared__ float sm_acc[4][G][128];
     __shared__ float sm_ml[4][G][2];
 
@@ -36,6 +48,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
 #pragma unroll
     for (int g = 0; g < G; ++g)
         qv[g] = *reinterpret_cast<const bf16x8*>(q + (int64_t)b * q_stride + (int64_t)(kvh * G + g) * 128 + c * 8);
+    bf16x8 k_new = {0, 0, 0, 0, 0, 0, 0, 0}, v_new = k_new;
+    if constexpr (FUSED) {
+        if (ctx > 0) {                                       // block-uniform
+            const float* cs_row = fz.cos_sin + fz.positions[b] * 128;
+            const bf16x8 qw = *reinterpret_cast<const bf16x8*>(fz.q_norm_w + c * 8);
+            const bf16x8 kw = *reinterpret_cast<const bf16x8*>(fz.k_norm_w + c * 8);
+#pragma unroll
+            for (int g = 0; g < G; ++g) qv[g] = qknorm_rope_head(qv[g], qw, cs_row, c, fz.eps);
+            const bf16* row = q + (int64_t)b * q_stride;
+            k_new = qknorm_rope_head(*reinterpret_cast<const bf16x8*>(row + (int64_t)(hq + kvh) * 128 + c * 8), kw, cs_row, c, fz.eps);
+            v_new = *reinterpret_cast<const bf16x8*>(row + (int64_t)(hq + hkv + kvh) * 128 + c * 8);
+        }
+    }
 
     float m[G], l[G], acc[G][8];
 #pragma unroll
@@ -58,6 +83,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
             const int64_t off = ((slot0 + (valid[u] ? toff : 0)) * hkv + kvh) * 128 + c * 8;
             kf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kc + off));   // streamed once
             vf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vc + off));
+            if constexpr (FUSED) {
+                if (base + toff == ctx - 1) {                // the new token: not in the cache yet
+                    kf[u] = k_new;
+                    vf[u] = v_new;
+                    *reinterpret_cast<bf16x8*>(kc + off) = k_new;
+                    *reinterpret_cast<bf16x8*>(vc + off) = v_new;
+                }
+            }
         }
         float s[G][4];
 #pragma unroll
@@ -227,30 +260,40 @@ extern "C" int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_
     return (int32_t)(want < 1 ? 1 : want);
 }
 
-extern "C" int32_t nvh_attn_decode(const void* q, int64_t q_token_stride, const void* k_cache, const void* v_cache,
-                                   const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
-                                   int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                                   float softmax_scale, void* out, int32_t num_splits, void* workspace,
-                                   nvh_stream_t stream) {
-    NVH_REQUIRE(q && k_cache && v_cache && context_lens && block_tables && out, NVH_EINVAL, "nvh_attn_decode: null pointer");
-    NVH_REQUIRE(head_dim == 128, NVH_ENOSYS, "nvh_attn_decode: head_dim %ld unsupported (128 only)", (long)head_dim);
-    NVH_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, NVH_EINVAL, "nvh_attn_decode: Hq %% Hkv != 0");
-    NVH_REQUIRE(q_token_stride % 8 == 0 && nvh_aligned16(q) && nvh_aligned16(k_cache) && nvh_aligned16(v_cache), NVH_EINVAL,
-                "nvh_attn_decode: 16-byte alignment required");
-    NVH_REQUIRE(num_splits >= 1 && num_splits <= 256 && (num_splits == 1 || workspace), NVH_EINVAL,
-                "nvh_attn_decode: num_splits %d needs a workspace", num_splits);
-    NVH_REQUIRE(batch <= 65535 && num_kv_heads <= 65535, NVH_EINVAL, "nvh_attn_decode: batch/heads exceed grid limits");
-    if (batch == 0) return NVH_OK;
-    const int g = (int)(num_q_heads / num_kv_heads);
-    float* ws_acc = (float*)workspace;
-    float* ws_ml = ws_acc ? ws_acc + batch * num_q_heads * num_splits * 128 : nullptr;
-    dim3 grid((unsigned)num_splits, (unsigned)num_kv_heads, (unsigned)batch);
-    const float sl2 = softmax_scale * LOG2E;
-    hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_DEC(GG)                                                                                              \
-    attn_decode_kernel<GG><<<grid, 256, 0, st>>>((const bf16*)q, q_token_stride, (const bf16*)k_cache,             \
-                                                 (const bf16*)v_cache, context_lens, block_tables, table_stride,   \
-                                                 (int)num_kv_heads, sl2, (bf16*)out, ws_acc, ws_ml)
+namespace {
+struct DecodeArgs {
+    const void* q;
+    int64_t q_token_stride;
+    void *k_cache, *v_cache;
+    const int32_t *context_lens, *block_tables;
+    int64_t table_stride, batch, num_q_heads, num_kv_heads, head_dim;
+    float softmax_scale;
+    void* out;
+    int32_t num_splits;
+    void* workspace;
+    hipStream_t st;
+};
+
+template <bool FUSED>
+int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz) {
+    NVH_REQUIRE(a.q && a.k_cache && a.v_cache && a.context_lens && a.block_tables && a.out, NVH_EINVAL, "%s: null pointer", name);
+    NVH_REQUIRE(a.head_dim == 128, NVH_ENOSYS, "%s: head_dim %ld unsupported (128 only)", name, (long)a.head_dim);
+    NVH_REQUIRE(a.num_kv_heads > 0 && a.num_q_heads % a.num_kv_heads == 0, NVH_EINVAL, "%s: Hq %% Hkv != 0", name);
+    NVH_REQUIRE(a.q_token_stride % 8 == 0 && nvh_aligned16(a.q) && nvh_aligned16(a.k_cache) && nvh_aligned16(a.v_cache), NVH_EINVAL,
+                "%s: 16-byte alignment required", name);
+    NVH_REQUIRE(a.num_splits >= 1 && a.num_splits <= 256 && (a.num_splits == 1 || a.workspace), NVH_EINVAL,
+                "%s: num_splits %d needs a workspace", name, a.num_splits);
+    NVH_REQUIRE(a.batch <= 65535 && a.num_kv_heads <= 65535, NVH_EINVAL, "%s: batch/heads exceed grid limits", name);
+    if (a.batch == 0) return NVH_OK;
+    const int g = (int)(a.num_q_heads / a.num_kv_heads);
+    float* ws_acc = (float*)a.workspace;
+    float* ws_ml = ws_acc ? ws_acc + a.batch * a.num_q_heads * a.num_splits * 128 : nullptr;
+    dim3 grid((unsigned)a.num_splits, (unsigned)a.num_kv_heads, (unsigned)a.batch);
+    const float sl2 = a.softmax_scale * LOG2E;
+#define LAUNCH_DEC(GG)                                                                                                  \
+    attn_decode_kernel<GG, FUSED><<<grid, 256, 0, a.st>>>((const bf16*)a.q, a.q_token_stride, (bf16*)a.k_cache, (bf16*)a.v_cache, \
+                                                          a.context_lens, a.block_tables, a.table_stride, (int)a.num_kv_heads, \
+                                                          sl2, (bf16*)a.out, ws_acc, ws_ml, fz)
     switch (g) {
         case 1: LAUNCH_DEC(1); break;
         case 2: LAUNCH_DEC(2); break;
@@ -258,13 +301,40 @@ extern "C" int32_t nvh_attn_decode(const void* q, int64_t q_token_stride, const 
         case 5: LAUNCH_DEC(5); break;
         case 8: LAUNCH_DEC(8); break;
         default:
-            nvh_set_error("nvh_attn_decode: group size Hq/Hkv = %d unsupported (1,2,4,5,8)", g);
+            nvh_set_error("%s: group size Hq/Hkv = %d unsupported (1,2,4,5,8)", name, g);
             return NVH_ENOSYS;
     }
 #undef LAUNCH_DEC
-    NVH_CHECK_LAUNCH("attn_decode");
-    if (num_splits > 1) {
-        return nvh_launch_attn_combine(ws_acc, ws_ml, out, batch * num_q_heads, num_splits, st);
-    }
+    NVH_CHECK_LAUNCH(name);
+    if (a.num_splits > 1)
+        return nvh_launch_attn_combine(ws_acc, ws_ml, a.out, a.batch * a.num_q_heads, a.num_splits, a.st);
     return NVH_OK;
+}
+}  // namespace
+
+extern "C" int32_t nvh_attn_decode(const void* q, int64_t q_token_stride, const void* k_cache, const void* v_cache,
+                                   const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                   int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                   float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                                   nvh_stream_t stream) {
+    DecodeArgs a{q, q_token_stride, const_cast<void*>(k_cache), const_cast<void*>(v_cache), context_lens, block_tables,
+                 table_stride, batch, num_q_heads, num_kv_heads, head_dim, softmax_scale, out, num_splits, workspace,
+                 (hipStream_t)stream};
+    return launch_decode<false>("nvh_attn_decode", a, FusedQkv{});
+}
+
+extern "C" int32_t nvh_attn_decode_fused_qkv(const void* qkv, int64_t token_stride, const void* q_norm_weight,
+                                             const void* k_norm_weight, float eps, const int64_t* positions,
+                                             const float* cos_sin, void* k_cache, void* v_cache,
+                                             const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                             int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                             float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                                             nvh_stream_t stream) {
+    NVH_REQUIRE(q_norm_weight && k_norm_weight && positions && cos_sin, NVH_EINVAL, "nvh_attn_decode_fused_qkv: null pointer");
+    NVH_REQUIRE(nvh_aligned16(q_norm_weight) && nvh_aligned16(k_norm_weight) && nvh_aligned16(cos_sin), NVH_EINVAL,
+                "nvh_attn_decode_fused_qkv: 16-byte alignment required");
+    DecodeArgs a{qkv, token_stride, k_cache, v_cache, context_lens, block_tables, table_stride, batch, num_q_heads,
+                 num_kv_heads, head_dim, softmax_scale, out, num_splits, workspace, (hipStream_t)stream};
+    return launch_decode<true>("nvh_attn_decode_fused_qkv", a,
+                               FusedQkv{(const bf16*)q_norm_weight, (const bf16*)k_norm_weight, positions, cos_sin, eps});
 }

@@ -80,3 +80,35 @@ __device__ __forceinline__ float wave_max(float x) {
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+// Per-head RMSNorm -> bf16 -> x weight -> bf16 -> half-split RoPE -> bf16 for one head of 128 elements held
+// by a 16-lane DPP row: lane c owns elements [8c, 8c+8).  The rotation partner (i +- 64) lives in lane c^8
+// and arrives through a row rotation by 8.  cs_row: fp32 [cos(64) | sin(64)] of the token's position.
+// Used by every kernel that applies the q/k epilogue, so they all produce identical bits.
+__device__ __forceinline__ bf16x8 qknorm_rope_head(bf16x8 x, bf16x8 w, const float* __restrict__ cs_row, int c, float eps) {
+    float v[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = bf2f(x[j]);
+        ss += v[j] * v[j];
+    }
+    ss = row16_sum(ss);
+    const float inv = 1.0f / sqrtf(ss / 128.0f + eps);
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs_row + 8 * (c & 7));
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs_row + 8 * (c & 7) + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs_row + 64 + 8 * (c & 7));
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(cs_row + 64 + 8 * (c & 7) + 4);
+    bf16x8 out;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float n = bf2f(f2bf(bf2f(f2bf(v[j] * inv)) * bf2f(w[j])));
+        const float p = NVH_DPP(n, 0x128);                       // row_ror:8 -> lane c^8's value
+        const float cs = j < 4 ? c0[j] : c1[j - 4];
+        const float sn = j < 4 ? s0[j] : s1[j - 4];
+        // first half: x1*cos - x2*sin (own = x1); second half: x2*cos + x1*sin (own = x2)
+        const float y = (c < 8) ? n * cs - p * sn : n * cs + p * sn;
+        out[j] = f2bf(y);
+    }
+    return out;
+}

@@ -210,43 +210,11 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
         return;
     }
     const bf16* w = (h < hq) ? qw : kw;
-    bf16x4 lo = *reinterpret_cast<const bf16x4*>(base + c * 4);
-    bf16x4 hi = *reinterpret_cast<const bf16x4*>(base + 64 + c * 4);
-    const bf16x4 wlo = *reinterpret_cast<const bf16x4*>(w + c * 4);
-    const bf16x4 whi = *reinterpret_cast<const bf16x4*>(w + 64 + c * 4);
-    float a[4], b[4];
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a[j] = bf2f(lo[j]);
-        b[j] = bf2f(hi[j]);
-    }
-    // Sum in element order within the lane (first half, then second half) - any order is
-    // within the stated tolerance; the reduction tree across lanes is fixed.
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ss += a[j] * a[j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ss += b[j] * b[j];
-    ss = row16_sum(ss);
-    const float inv = 1.0f / sqrtf(ss / 128.0f + eps);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a[j] = bf2f(f2bf(bf2f(f2bf(a[j] * inv)) * bf2f(wlo[j])));
-        b[j] = bf2f(f2bf(bf2f(f2bf(b[j] * inv)) * bf2f(whi[j])));
-    }
-    const int64_t pos = positions[t];
-    const f32x4 cs = *reinterpret_cast<const f32x4*>(cos_sin + pos * 128 + c * 4);
-    const f32x4 sn = *reinterpret_cast<const f32x4*>(cos_sin + pos * 128 + 64 + c * 4);
-    rope_rotate(a, b, cs, sn);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { lo[j] = f2bf(a[j]); hi[j] = f2bf(b[j]); }
-    *reinterpret_cast<bf16x4*>(base + c * 4) = lo;
-    *reinterpret_cast<bf16x4*>(base + 64 + c * 4) = hi;
-    if (h >= hq && slot >= 0) {
-        bf16* dst = k_cache + (slot * hkv + (h - hq)) * 128;
-        *reinterpret_cast<bf16x4*>(dst + c * 4) = lo;
-        *reinterpret_cast<bf16x4*>(dst + 64 + c * 4) = hi;
-    }
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(base + c * 8);
+    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
+    const bf16x8 y = qknorm_rope_head(x, wv, cos_sin + positions[t] * 128, c, eps);
+    *reinterpret_cast<bf16x8*>(base + c * 8) = y;
+    if (h >= hq && slot >= 0) *reinterpret_cast<bf16x8*>(k_cache + (slot * hkv + (h - hq)) * 128 + c * 8) = y;
 }
 
 extern "C" int32_t nvh_qknorm_rope_store(void* qkv, int64_t token_stride, int64_t num_q_heads, int64_t num_kv_heads,

@@ -2,6 +2,7 @@
 // cost of a step is ~250 HIP launches instead of ~250 Python -> ctypes round trips.  It calls the
 // same entry points a caller would call one by one (identical kernels, order and rounding).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 constexpr int32_t kMaxVarlenSplits = 8;
@@ -94,18 +95,26 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
         void* kc = md->k_cache ? md->k_cache[l] : nullptr;
         void* vc = md->v_cache ? md->v_cache[l] : nullptr;
         const bool store = kc && vc && st->slot_mapping;
-        FWD(nvh_qknorm_rope_store(w.qkv, qkv_n, hq, hkv, md->q_norm[l], md->k_norm[l], md->eps, st->positions,
-                                  md->cos_sin, md->max_position, store ? kc : nullptr, store ? vc : nullptr,
-                                  store ? st->slot_mapping : nullptr, t, stream));
-        if (st->mode == NVH_MODE_DECODE) {
-            FWD(nvh_attn_decode(w.qkv, qkv_n, kc, vc, st->context_lens, st->block_tables, st->table_stride, b, hq, hkv,
-                                d, scale, w.attn, dsplits, w.decode_ws, stream));
-        } else if (st->mode == NVH_MODE_PAGED) {
-            FWD(nvh_attn_varlen(w.qkv, qkv_n, kc, vc, kvsz, st->cu_seqlens_q, st->cu_seqlens_k, st->block_tables,
-                                st->table_stride, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
+        static const bool fuse_decode = getenv("NVH_NO_FUSED_DECODE") == nullptr;   // A/B switch for measurements
+        if (st->mode == NVH_MODE_DECODE && store && fuse_decode) {
+            // one launch: q/k norm + RoPE + KV store of the new token + attention
+            FWD(nvh_attn_decode_fused_qkv(w.qkv, qkv_n, md->q_norm[l], md->k_norm[l], md->eps, st->positions, md->cos_sin, kc, vc,
+                                          st->context_lens, st->block_tables, st->table_stride, b, hq, hkv, d, scale, w.attn,
+                                          dsplits, w.decode_ws, stream));
         } else {
-            FWD(nvh_attn_varlen(w.qkv, qkv_n, w.qkv + qsz, w.qkv + qsz + kvsz, qkv_n, st->cu_seqlens_q, st->cu_seqlens_k,
-                                nullptr, 0, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
+            FWD(nvh_qknorm_rope_store(w.qkv, qkv_n, hq, hkv, md->q_norm[l], md->k_norm[l], md->eps, st->positions,
+                                      md->cos_sin, md->max_position, store ? kc : nullptr, store ? vc : nullptr,
+                                      store ? st->slot_mapping : nullptr, t, stream));
+            if (st->mode == NVH_MODE_DECODE) {
+                FWD(nvh_attn_decode(w.qkv, qkv_n, kc, vc, st->context_lens, st->block_tables, st->table_stride, b, hq, hkv,
+                                    d, scale, w.attn, dsplits, w.decode_ws, stream));
+            } else if (st->mode == NVH_MODE_PAGED) {
+                FWD(nvh_attn_varlen(w.qkv, qkv_n, kc, vc, kvsz, st->cu_seqlens_q, st->cu_seqlens_k, st->block_tables,
+                                    st->table_stride, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
+            } else {
+                FWD(nvh_attn_varlen(w.qkv, qkv_n, w.qkv + qsz, w.qkv + qsz + kvsz, qkv_n, st->cu_seqlens_q, st->cu_seqlens_k,
+                                    nullptr, 0, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
+            }
         }
         // ---- O projection -> add + norm
         if (so > 1) {

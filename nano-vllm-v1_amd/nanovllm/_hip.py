@@ -37,6 +37,7 @@ SIGNATURES = {
     "nvh_attn_varlen_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_varlen_suggest_splits": (i32, [i64, i64, i64, i64, i64]),
     "nvh_attn_decode": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
+    "nvh_attn_decode_fused_qkv": (i32, [vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
     "nvh_attn_decode_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_decode_suggest_splits": (i32, [i64, i64, i64]),
     "nvh_sample_workspace_bytes": (i64, [i64, i64]),

@@ -260,6 +260,30 @@ def attn_decode(q, k_cache, v_cache, context_lens, block_tables, scale: float, n
     return out
 
 
+def attn_decode_fused_qkv(qkv, num_q_heads: int, num_kv_heads: int, q_weight, k_weight, eps: float, positions, cos_sin,
+                          k_cache, v_cache, context_lens, block_tables, scale: float, num_splits: int = 0,
+                          max_context: int | None = None) -> torch.Tensor:
+    """Decode attention straight from the raw fused qkv rows [B, (Hq+2Hkv)*128]: q/k norm + RoPE + KV store +
+    attention in one launch."""
+    _gpu_bf16(qkv, q_weight, k_weight, k_cache, v_cache)
+    b, d = qkv.shape[0], 128
+    assert qkv.stride(1) == 1 and k_cache.is_contiguous() and v_cache.is_contiguous() and positions.dtype == torch.int64
+    if num_splits <= 0:
+        mc = max_context if max_context is not None else block_tables.shape[1] * KV_PAGE
+        num_splits = suggest_decode_splits(b, num_kv_heads, mc)
+    out = torch.empty(b, num_q_heads, d, dtype=BF16, device=qkv.device)
+    ws = 0
+    if num_splits > 1:
+        ws_t = torch.empty(_hip.lib().nvh_attn_decode_workspace_bytes(b, num_q_heads, d, num_splits) // 4,
+                           dtype=torch.float32, device=qkv.device)
+        ws = ws_t.data_ptr()
+    _hip.call("nvh_attn_decode_fused_qkv", qkv.data_ptr(), qkv.stride(0), q_weight.data_ptr(), k_weight.data_ptr(), float(eps),
+              positions.data_ptr(), cos_sin.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), context_lens.data_ptr(),
+              block_tables.data_ptr(), block_tables.stride(0), b, num_q_heads, num_kv_heads, d, float(scale), out.data_ptr(),
+              num_splits, ws, _stream())
+    return out
+
+
 # ---------------------------------------------------------------- sampling
 def _logits_args(logits):
     assert logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1

@@ -57,7 +57,7 @@ def assert_gemm(got, ref, max_frac=0.03):
 
 
 def assert_exact(got, ref):
-    got = got.cpu()
+    got, ref = got.cpu(), ref.cpu()
     assert got.shape == ref.shape and torch.equal(got, ref), f"mismatch: {int((got != ref).sum())} elements"
 
 
@@ -181,14 +181,14 @@ def test_fused_qknorm_rope_store_equals_sequence(ops):
     assert_exact(vd, v)                                   # v untouched
     assert_exact(vcd, vc)                                 # v scatter is a pure copy
     assert_exact(kcd[0][slots[slots >= 0].long()], kd.reshape(t, hkv, d)[slots >= 0])   # cache rows == rotated k rows
-    # same arithmetic as the three separate entry points
+    # the separate entry points sum the squares in a different lane order: at most the last bit moves
     qkv_s = dev(qkv.clone())
     qs, ks, vs = qkv_s.split([hq * d, hkv * d, hkv * d], dim=-1)
     qn_d = ops.rmsnorm(qs.reshape(t, hq, d), dev(qw), 1e-6)
     kn_d = ops.rmsnorm(ks.reshape(t, hkv, d), dev(kw), 1e-6)
     ops.rope_(dev(pos), qn_d, kn_d, dev(table.squeeze(1).contiguous()))
-    assert_exact(qn_d, qd.reshape(t, hq, d))
-    assert_exact(kn_d, kd.reshape(t, hkv, d))
+    assert_ulp(qn_d.cpu(), qd.reshape(t, hq, d), max_ulp=1, max_frac=0.01)
+    assert_ulp(kn_d.cpu(), kd.reshape(t, hkv, d), max_ulp=1, max_frac=0.01)
 
 
 def test_silu_mul_shapes(ops):
@@ -278,6 +278,37 @@ def test_attn_decode_vs_oracle(ops, hq, hkv, splits):
     got = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=splits)
     assert_close(got, ref, 1.5e-2, 2e-2)
     assert float(got[6].abs().max()) == 0.0             # padded row (length 0) -> zeros
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (4, 4), (8, 2), (10, 2), (8, 1)])
+@pytest.mark.parametrize("splits", [1, 5])
+def test_attn_decode_fused_qkv_equals_sequence(ops, hq, hkv, splits):
+    """One launch (norm + RoPE + store + attention from raw qkv) == qknorm_rope_store then attn_decode, bit for bit."""
+    d = 128
+    lens_k = [1, 255, 256, 257, 1000, 64, 0, 700]
+    b = len(lens_k)
+    _, kc, vc, bt, _, _ = _paged_case(70 + hq, [1] * b, lens_k, hq, hkv)
+    qkv = rnd(b, (hq + 2 * hkv) * d, seed=71, scale=1.5)
+    qw, kw = (rnd(d, seed=72).float() * 0.2 + 1).to(BF), (rnd(d, seed=73).float() * 0.2 + 1).to(BF)
+    ctx = torch.tensor(lens_k, dtype=torch.int32)
+    pos = (ctx.long() - 1).clamp(min=0)
+    slots = torch.tensor([int(bt[i, (n - 1) // 256]) * 256 + (n - 1) % 256 if n > 0 else -1 for i, n in enumerate(lens_k)],
+                         dtype=torch.int32)
+    table = dev(R.rope_table(128, 4096, 1e6).squeeze(1).contiguous())
+    scale = d ** -0.5
+    # sequence of two launches
+    qkv_a, kca, vca = dev(qkv.clone()), dev(kc.clone()), dev(vc.clone())
+    ops.qknorm_rope_store_(qkv_a, hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), table, kca, vca, dev(slots))
+    ref = ops.attn_decode(qkv_a[:, :hq * d].view(b, hq, d), kca, vca, dev(ctx), dev(bt), scale, num_splits=splits)
+    # fused launch
+    qkv_b, kcb, vcb = dev(qkv.clone()), dev(kc.clone()), dev(vc.clone())
+    got = ops.attn_decode_fused_qkv(qkv_b, hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), table, kcb, vcb, dev(ctx), dev(bt),
+                                    scale, num_splits=splits)
+    assert_exact(got, ref)
+    assert_exact(kcb, kca)
+    assert_exact(vcb, vca)
+    assert_exact(qkv_b.cpu(), qkv)                       # raw projection left untouched
+    assert float(got[6].abs().max()) == 0.0
 
 
 def test_attn_decode_strided_q_long_context(ops):
