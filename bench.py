@@ -95,22 +95,29 @@ class Driver:
                 toks, need = self.runner.run([s])
                 torch.cuda.synchronize()
                 times.append((time.perf_counter() - t0, n, s.num_cached_tokens))
+                toks = self.share_tokens(toks, int(need.numel()))
                 s.num_cached_tokens += n
                 s.num_new_tokens = 0
                 if toks:
                     s.append_token(toks[0])
         return times
 
+    @staticmethod
+    def share_tokens(toks, n):
+        """Only rank 0 samples; every rank must feed the same ids to the next step (the engine's control
+        plane does this with the scheduler's sequences; here one small broadcast stands in for it)."""
+        if n and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor(toks if toks is not None else [0] * n, dtype=torch.int64, device="cuda")
+            dist.broadcast(t, 0)
+            toks = t.tolist()
+        return toks
+
     def decode_step(self, seqs):
         for s in seqs:
             s.num_new_tokens = 1
             self.grow(s, s.num_cached_tokens + 1)
         toks, need = self.runner.run(seqs)
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            # only rank 0 samples; every rank must feed the same ids to the next step
-            t = torch.tensor(toks if toks is not None else [0] * len(seqs), dtype=torch.int64, device="cuda")
-            dist.broadcast(t, 0)
-            toks = t.tolist()
+        toks = self.share_tokens(toks, len(seqs))
         for s, t in zip(seqs, toks):
             s.num_cached_tokens += 1
             s.num_new_tokens = 0
@@ -236,10 +243,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py: for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+    # Rehearsal on a one-GPU box: NANOVLLM_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 with gloo as the
+    # control plane (RCCL refuses two ranks on one device); the data path is the xGMI exchange either way.
+    share_device = os.environ.get("NANOVLLM_BENCH_SHARE_DEVICE", "0") == "1"
+    if share_device:
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from nanovllm.config import Config
     from nanovllm.engine.model_runner import ModelRunner
@@ -291,6 +307,11 @@ def main():
                                   frac=round(step_gbs / HBM_PEAK_GBS, 4), bytes_per_step=int(step_bytes),
                                   weight_bytes=int(w_bytes), kv_bytes_per_context_token=int(kv_tok)),
                prefill=prefill, init_s=round(init_s, 1))
+    if distributed:
+        out["tp_exchange"] = ("xgmi peer all-reduce (one kernel per projection, inside the native step and its hipGraph)"
+                              if runner.comm is not None else "torch.distributed (RCCL) between operator modules")
+        if share_device:
+            out["config"]["rehearsal"] = "all ranks share cuda:0; not a scaling measurement"
     out["roofline"] = kernel_roofline(runner, seqs, iters=4)
 
     if not args.no_extras:

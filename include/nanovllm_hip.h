@@ -191,9 +191,38 @@ int32_t nvh_sample_with_noise(const void* logits, int32_t logits_is_f32, int64_t
 int32_t nvh_argmax(const void* logits, int32_t logits_is_f32, int64_t row_stride, int64_t* out,
                    int64_t rows, int64_t vocab, void* workspace, nvh_stream_t stream);
 
+/* ---- C1/C2: tensor-parallel exchange over xGMI peer mappings.
+ * Replaces the NCCL all-reduce after every row-parallel projection (layers/linear.py:407-409) and after the
+ * vocabulary-parallel embedding (layers/embed_head.py:128-129).  One rank per process and device.
+ * nvh_comm_create allocates this rank's exchange region (flags + `max_bytes` of staging; the only allocation
+ * in the library, made once at start-up); the ranks swap nvh_comm_get_handle() blobs of
+ * nvh_comm_handle_bytes() each over any control channel and pass them, in rank order, to
+ * nvh_comm_open_peers.  nvh_allreduce_bf16 is then one asynchronous, hipGraph-capturable kernel per rank:
+ * `out` = sum over ranks of `in` (fp32 accumulation in rank order, so every rank gets the same bits),
+ * count % 8 == 0, count*2 <= max_bytes.  `in` may be nvh_comm_buffer() itself (a producer wrote there; no
+ * staging copy) or any other device pointer; `out` must lie outside the staging area and may equal `in`
+ * otherwise.  All ranks must issue the same sequence of calls with the same counts.  A rank that waits more
+ * than 20 s for a peer records a fault and lets its grid drain; nvh_comm_error (synchronises) reports it. */
+typedef struct nvh_comm nvh_comm;
+int32_t nvh_comm_handle_bytes(void);
+int32_t nvh_comm_create(int32_t rank, int32_t world, int64_t max_bytes, nvh_comm** out);
+int32_t nvh_comm_get_handle(nvh_comm* comm, void* handle_out);
+int32_t nvh_comm_open_peers(nvh_comm* comm, const void* handles);
+void* nvh_comm_buffer(nvh_comm* comm);
+int64_t nvh_comm_max_bytes(nvh_comm* comm);
+int32_t nvh_allreduce_bf16(nvh_comm* comm, const void* in, void* out, int64_t count, nvh_stream_t stream);
+/* C3: logits gather of ParallelLMHead.forward (layers/embed_head.py:205-209): on `root`,
+ * out[rows, world*cols] = column-wise concatenation in rank order of every rank's in[rows, cols]
+ * (cols % 8 == 0, rows*cols*2 <= max_bytes); `out` is ignored on the other ranks. */
+int32_t nvh_gather_cols_bf16(nvh_comm* comm, const void* in, void* out, int64_t rows, int64_t cols, int32_t root,
+                             nvh_stream_t stream);
+int32_t nvh_comm_error(nvh_comm* comm);
+int32_t nvh_comm_destroy(nvh_comm* comm);
+
 /* ---- whole-model executor: the layer loop of models/qwen3.py:401-441 (Qwen3Model.forward) and
  * compute_logits (:509-533), issued from native code so one call enqueues every kernel of a step
- * (single rank; tensor-parallel runs use the operator modules + RCCL between them).
+ * (one rank's share of the model; with `comm` set the row-parallel outputs and the embedding are summed
+ * and the logits gathered through the xGMI exchange above, otherwise the rank stands alone).
  * Same kernels, same order and same rounding points as calling the entry points above one by one:
  *   embedding -> L x { (add+)RMSNorm -> QKV GEMM -> q/k norm + RoPE + KV store -> attention ->
  *   O GEMM (split-K slabs) -> add+RMSNorm (sums slabs) -> gate/up GEMM -> SiLU*mul -> down GEMM } ->
@@ -201,7 +230,7 @@ int32_t nvh_argmax(const void* logits, int32_t logits_is_f32, int64_t row_stride
  * All pointer arrays have `layers` entries and live in HOST memory; they are read during the call only. */
 typedef struct {
     int32_t hidden, layers, num_q_heads, num_kv_heads, head_dim, inter;
-    int32_t vocab_rows, reserved;
+    int32_t vocab_rows, vocab_start;   /* this rank's rows of the vocabulary: [vocab_start, vocab_start + vocab_rows) */
     float eps;
     int32_t reserved2;
     int64_t max_position;
@@ -220,6 +249,7 @@ typedef struct {
     const void* const* post_norm;      /* [hidden] */
     void* const* k_cache;              /* [pages,256,Hkv,D] per layer, or NULL array entries before the pool exists */
     void* const* v_cache;
+    nvh_comm* comm;                    /* NULL: single rank.  Else all sizes above are this rank's shard */
 } nvh_qwen3_model;
 
 #define NVH_MODE_PACKED 0   /* layers/attention.py: block_tables is None (K/V = new tokens) */
@@ -245,7 +275,8 @@ int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_toke
 int32_t nvh_qwen3_forward(const nvh_qwen3_model* model, const nvh_step* step, void* hidden_out,
                           void* workspace, int64_t workspace_bytes, nvh_stream_t stream);
 /* logits [num_rows, vocab_rows] bf16 = lm_head(hidden[last rows]); layers/embed_head.py:197-204.
- * rows_ws: bf16 [num_rows, hidden] scratch; cu_seqlens_q NULL -> hidden rows are used as they are. */
+ * rows_ws: bf16 [num_rows, hidden] scratch; cu_seqlens_q NULL -> hidden rows are used as they are.
+ * With `comm` set: logits is [num_rows, world*vocab_rows] on rank 0 (:205-209) and unused (may be NULL) elsewhere. */
 int32_t nvh_qwen3_logits(const nvh_qwen3_model* model, const void* hidden, const int32_t* cu_seqlens_q,
                          const int32_t* need, int64_t num_rows, void* rows_ws, void* logits, nvh_stream_t stream);
 

@@ -1,0 +1,287 @@
+// Tensor-parallel exchange over xGMI without a collective library on the data path.
+//
+// Every rank owns one uncached (fine-grained) device region, exported to its peers through HIP IPC:
+//     [ flags: kMaxBlocks x 8 x u32 | staging: max_bytes ]
+// An all-reduce is ONE kernel per rank.  Block i of every rank works on the same element range i, so a
+// per-block flag exchange between the ranks is all the synchronisation there is:
+//     (stage range i of the input into the own staging area)  ->  barrier  ->  sum range i over all ranks'
+//     staging areas in rank order (every rank gets identical bits)  ->  barrier (staging may be rewritten).
+// Messages above kTwoShotBytes reduce-scatter in place and then gather, reading 2(w-1)/w of the message per
+// rank instead of (w-1).  Flags are monotonically increasing epochs kept in device memory, so the kernels
+// replay inside a hipGraph.  Every spin is bounded by a wall-clock limit; on expiry the rank records the
+// fault (nvh_comm_error) and lets the grid drain instead of hanging the device.
+//
+// Replaces the NCCL all-reduce of RowParallelLinear.forward (reference layers/linear.py:407-409) and of
+// VocabParallelEmbedding.forward (layers/embed_head.py:128-129).
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+constexpr int kMaxWorld = 8;
+constexpr int kMaxBlocks = 128;
+constexpr int kThreads = 512;
+constexpr int64_t kFlagBytes = (int64_t)kMaxBlocks * kMaxWorld * sizeof(uint32_t);
+constexpr int64_t kTwoShotBytes = 1 << 20;
+constexpr uint64_t kSpinLimitTicks = 20ull * 100000000ull;   // 20 s of the 100 MHz wall clock
+
+struct CommDev {                    // passed to kernels by value
+    uint32_t* flags[kMaxWorld];     // flags[r]: rank r's flag block (own or IPC-mapped)
+    bf16* stage[kMaxWorld];         // stage[r]: rank r's staging area
+    uint32_t* epoch;                // [kMaxBlocks] own device memory: barriers passed so far per block
+    uint32_t* fault;                // own device memory: nonzero once a spin timed out
+    int rank, world;
+};
+
+}  // namespace
+
+struct nvh_comm {
+    CommDev dev;
+    void* region;                   // own uncached region
+    void* peer_base[kMaxWorld];     // IPC-mapped peer regions (nullptr for self)
+    void* local;                    // epoch + fault words
+    int64_t max_bytes;
+    bool opened;
+};
+
+namespace {
+
+// Epoch e has been reached by every rank's block blockIdx.x once this returns.  `release`: this block wrote
+// data the peers will read after the barrier.
+__device__ __forceinline__ void comm_barrier(const CommDev& c, uint32_t e, bool release) {
+    if (release) __threadfence_system();
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < c.world) {
+        __hip_atomic_store(c.flags[t] + blockIdx.x * kMaxWorld + c.rank, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t* mine = c.flags[c.rank] + blockIdx.x * kMaxWorld + t;
+        const uint64_t t0 = wall_clock64();
+        while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > kSpinLimitTicks) {
+                __hip_atomic_store(c.fault, 1u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: drop every line cached before the barrier
+}
+
+__device__ __forceinline__ bf16x8 sum_ranks(const CommDev& c, int64_t pack) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    bf16x8 v[kMaxWorld];
+#pragma unroll
+    for (int r = 0; r < kMaxWorld; ++r)
+        if (r < c.world) v[r] = reinterpret_cast<const bf16x8*>(c.stage[r])[pack];
+#pragma unroll
+    for (int r = 0; r < kMaxWorld; ++r)
+        if (r < c.world)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += bf2f(v[r][j]);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(acc[j]);
+    return o;
+}
+
+// packs: 16-byte units of the message.  Block b owns packs [b*per, min((b+1)*per, packs)).
+__global__ __launch_bounds__(kThreads) void allreduce_oneshot_kernel(CommDev c, const bf16* __restrict__ in, bf16* __restrict__ out,
+                                                                     int64_t packs, int64_t per, int staged) {
+    const uint32_t e0 = c.epoch[blockIdx.x];
+    const int64_t lo = blockIdx.x * per, hi = min(lo + per, packs);
+    if (staged)
+        for (int64_t p = lo + threadIdx.x; p < hi; p += kThreads)
+            reinterpret_cast<bf16x8*>(c.stage[c.rank])[p] = reinterpret_cast<const bf16x8*>(in)[p];
+    comm_barrier(c, e0 + 1, staged);
+    for (int64_t p = lo + threadIdx.x; p < hi; p += kThreads) reinterpret_cast<bf16x8*>(out)[p] = sum_ranks(c, p);
+    comm_barrier(c, e0 + 2, false);
+    if (threadIdx.x == 0) c.epoch[blockIdx.x] = e0 + 2;
+}
+
+// Slice s = packs [s*slice, min((s+1)*slice, packs)) is reduced by rank s.  Block b owns sub-range
+// [b*per, (b+1)*per) of EVERY slice, on every rank, so the per-block barrier covers all the hand-offs.
+__global__ __launch_bounds__(kThreads) void allreduce_twoshot_kernel(CommDev c, const bf16* __restrict__ in, bf16* __restrict__ out,
+                                                                     int64_t packs, int64_t slice, int64_t per, int staged) {
+    const uint32_t e0 = c.epoch[blockIdx.x];
+    const int64_t sub_lo = blockIdx.x * per, sub_hi = min(sub_lo + per, slice);
+    if (staged)
+        for (int s = 0; s < c.world; ++s)
+            for (int64_t q = sub_lo + threadIdx.x; q < sub_hi; q += kThreads) {
+                const int64_t p = s * slice + q;
+                if (p < packs) reinterpret_cast<bf16x8*>(c.stage[c.rank])[p] = reinterpret_cast<const bf16x8*>(in)[p];
+            }
+    comm_barrier(c, e0 + 1, staged);
+    for (int64_t q = sub_lo + threadIdx.x; q < sub_hi; q += kThreads) {          // reduce own slice in place
+        const int64_t p = c.rank * slice + q;
+        if (p < packs) reinterpret_cast<bf16x8*>(c.stage[c.rank])[p] = sum_ranks(c, p);
+    }
+    comm_barrier(c, e0 + 2, true);
+    for (int s = 0; s < c.world; ++s)
+        for (int64_t q = sub_lo + threadIdx.x; q < sub_hi; q += kThreads) {
+            const int64_t p = s * slice + q;
+            if (p < packs) reinterpret_cast<bf16x8*>(out)[p] = reinterpret_cast<const bf16x8*>(c.stage[s])[p];
+        }
+    comm_barrier(c, e0 + 3, false);
+    if (threadIdx.x == 0) c.epoch[blockIdx.x] = e0 + 3;
+}
+
+// Column-wise concatenation on `root`: out[row, r*cols + j] = rank r's in[row, j].  Same block-range ownership as
+// the one-shot all-reduce; ranks other than root only stage and take part in the two barriers.
+__global__ __launch_bounds__(kThreads) void gather_cols_kernel(CommDev c, const bf16* __restrict__ in, bf16* __restrict__ out,
+                                                               int64_t cols8, int64_t packs, int64_t per, int staged, int root) {
+    const uint32_t e0 = c.epoch[blockIdx.x];
+    const int64_t lo = blockIdx.x * per, hi = min(lo + per, packs);
+    if (staged)
+        for (int64_t p = lo + threadIdx.x; p < hi; p += kThreads)
+            reinterpret_cast<bf16x8*>(c.stage[c.rank])[p] = reinterpret_cast<const bf16x8*>(in)[p];
+    comm_barrier(c, e0 + 1, staged);
+    if (c.rank == root)
+        for (int64_t p = lo + threadIdx.x; p < hi; p += kThreads) {
+            const int64_t row = p / cols8, col = p - row * cols8;
+            for (int r = 0; r < c.world; ++r)
+                reinterpret_cast<bf16x8*>(out)[(row * c.world + r) * cols8 + col] = reinterpret_cast<const bf16x8*>(c.stage[r])[p];
+        }
+    comm_barrier(c, e0 + 2, false);
+    if (threadIdx.x == 0) c.epoch[blockIdx.x] = e0 + 2;
+}
+
+}  // namespace
+
+extern "C" int32_t nvh_comm_handle_bytes(void) { return (int32_t)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int32_t nvh_comm_create(int32_t rank, int32_t world, int64_t max_bytes, nvh_comm** out) {
+    NVH_REQUIRE(out, NVH_EINVAL, "nvh_comm_create: null out");
+    NVH_REQUIRE(world >= 2 && world <= kMaxWorld && rank >= 0 && rank < world, NVH_EINVAL, "nvh_comm_create: rank %d / world %d (2..%d)",
+                rank, world, kMaxWorld);
+    NVH_REQUIRE(max_bytes > 0 && max_bytes % 16 == 0, NVH_EINVAL, "nvh_comm_create: max_bytes must be a positive multiple of 16");
+    nvh_comm* c = new nvh_comm();
+    memset(c, 0, sizeof(*c));
+    c->max_bytes = max_bytes;
+    c->dev.rank = rank;
+    c->dev.world = world;
+    hipError_t e = hipExtMallocWithFlags(&c->region, kFlagBytes + max_bytes, hipDeviceMallocUncached);
+    if (e == hipSuccess) e = hipMemset(c->region, 0, kFlagBytes);
+    if (e == hipSuccess) e = hipMalloc(&c->local, (kMaxBlocks + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->local, 0, (kMaxBlocks + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        nvh_set_error("nvh_comm_create: %s", hipGetErrorString(e));
+        if (c->region) (void)hipFree(c->region);
+        if (c->local) (void)hipFree(c->local);
+        delete c;
+        return NVH_ELAUNCH;
+    }
+    c->dev.epoch = (uint32_t*)c->local;
+    c->dev.fault = c->dev.epoch + kMaxBlocks;
+    c->dev.flags[rank] = (uint32_t*)c->region;
+    c->dev.stage[rank] = (bf16*)((char*)c->region + kFlagBytes);
+    *out = c;
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_comm_get_handle(nvh_comm* c, void* handle_out) {
+    NVH_REQUIRE(c && handle_out, NVH_EINVAL, "nvh_comm_get_handle: null pointer");
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, c->region);
+    NVH_REQUIRE(e == hipSuccess, NVH_ELAUNCH, "nvh_comm_get_handle: %s", hipGetErrorString(e));
+    memcpy(handle_out, &h, sizeof(h));
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_comm_open_peers(nvh_comm* c, const void* handles) {
+    NVH_REQUIRE(c && handles, NVH_EINVAL, "nvh_comm_open_peers: null pointer");
+    NVH_REQUIRE(!c->opened, NVH_EINVAL, "nvh_comm_open_peers: already opened");
+    for (int r = 0; r < c->dev.world; ++r) {
+        if (r == c->dev.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char*)handles + (size_t)r * sizeof(h), sizeof(h));
+        void* base = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+        NVH_REQUIRE(e == hipSuccess, NVH_ELAUNCH, "nvh_comm_open_peers: rank %d cannot map rank %d: %s", c->dev.rank, r, hipGetErrorString(e));
+        c->peer_base[r] = base;
+        c->dev.flags[r] = (uint32_t*)base;
+        c->dev.stage[r] = (bf16*)((char*)base + kFlagBytes);
+    }
+    c->opened = true;
+    return NVH_OK;
+}
+
+extern "C" void* nvh_comm_buffer(nvh_comm* c) { return c ? (void*)c->dev.stage[c->dev.rank] : nullptr; }
+extern "C" int64_t nvh_comm_max_bytes(nvh_comm* c) { return c ? c->max_bytes : 0; }
+
+extern "C" int32_t nvh_allreduce_bf16(nvh_comm* c, const void* in, void* out, int64_t count, nvh_stream_t stream) {
+    NVH_REQUIRE(c && in && out, NVH_EINVAL, "nvh_allreduce_bf16: null pointer");
+    NVH_REQUIRE(c->opened, NVH_EINVAL, "nvh_allreduce_bf16: peers not mapped (nvh_comm_open_peers)");
+    NVH_REQUIRE(count >= 0 && count % 8 == 0 && count * 2 <= c->max_bytes, NVH_EINVAL,
+                "nvh_allreduce_bf16: count %ld must be a multiple of 8 and fit %ld staging bytes", (long)count, (long)c->max_bytes);
+    NVH_REQUIRE(nvh_aligned16(in) && nvh_aligned16(out), NVH_EINVAL, "nvh_allreduce_bf16: 16-byte alignment required");
+    const char* own = (const char*)c->dev.stage[c->dev.rank];
+    const bool in_place = (const char*)in == own;
+    NVH_REQUIRE(in_place || (const char*)in + count * 2 <= own || (const char*)in >= own + c->max_bytes, NVH_EINVAL,
+                "nvh_allreduce_bf16: input overlaps the staging area without starting at it");
+    NVH_REQUIRE((const char*)out + count * 2 <= own || (const char*)out >= own + c->max_bytes, NVH_EINVAL,
+                "nvh_allreduce_bf16: output must lie outside the staging area");
+    if (count == 0) return NVH_OK;
+    const int64_t packs = count / 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (count * 2 <= kTwoShotBytes) {
+        const int nb = (int)std::min<int64_t>(kMaxBlocks / 2, nvh_cdiv(packs, kThreads));
+        const int64_t per = nvh_cdiv(packs, nb);
+        allreduce_oneshot_kernel<<<nb, kThreads, 0, st>>>(c->dev, (const bf16*)in, (bf16*)out, packs, per, in_place ? 0 : 1);
+    } else {
+        const int64_t slice = nvh_cdiv(packs, c->dev.world);
+        const int nb = (int)std::min<int64_t>(kMaxBlocks, nvh_cdiv(slice, kThreads));
+        const int64_t per = nvh_cdiv(slice, nb);
+        allreduce_twoshot_kernel<<<nb, kThreads, 0, st>>>(c->dev, (const bf16*)in, (bf16*)out, packs, slice, per, in_place ? 0 : 1);
+    }
+    NVH_CHECK_LAUNCH("nvh_allreduce_bf16");
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_gather_cols_bf16(nvh_comm* c, const void* in, void* out, int64_t rows, int64_t cols, int32_t root,
+                                        nvh_stream_t stream) {
+    NVH_REQUIRE(c && in, NVH_EINVAL, "nvh_gather_cols_bf16: null pointer");
+    NVH_REQUIRE(c->opened, NVH_EINVAL, "nvh_gather_cols_bf16: peers not mapped (nvh_comm_open_peers)");
+    NVH_REQUIRE(root >= 0 && root < c->dev.world && (c->dev.rank != root || out), NVH_EINVAL, "nvh_gather_cols_bf16: bad root / null out on root");
+    NVH_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && rows * cols * 2 <= c->max_bytes, NVH_EINVAL,
+                "nvh_gather_cols_bf16: [%ld, %ld] needs cols %% 8 == 0 and must fit %ld staging bytes", (long)rows, (long)cols, (long)c->max_bytes);
+    NVH_REQUIRE(nvh_aligned16(in) && nvh_aligned16(out), NVH_EINVAL, "nvh_gather_cols_bf16: 16-byte alignment required");
+    const char* own = (const char*)c->dev.stage[c->dev.rank];
+    const bool in_place = (const char*)in == own;
+    NVH_REQUIRE(in_place || (const char*)in + rows * cols * 2 <= own || (const char*)in >= own + c->max_bytes, NVH_EINVAL,
+                "nvh_gather_cols_bf16: input overlaps the staging area without starting at it");
+    if (rows == 0) return NVH_OK;
+    const int64_t packs = rows * cols / 8;
+    const int nb = (int)std::min<int64_t>(kMaxBlocks, nvh_cdiv(packs, kThreads));
+    gather_cols_kernel<<<nb, kThreads, 0, (hipStream_t)stream>>>(c->dev, (const bf16*)in, (bf16*)out, cols / 8, packs, nvh_cdiv(packs, nb),
+                                                                 in_place ? 0 : 1, root);
+    NVH_CHECK_LAUNCH("nvh_gather_cols_bf16");
+    return NVH_OK;
+}
+
+// Synchronises the device; returns 0 when no exchange has timed out, else 1 + the first silent rank seen.
+extern "C" int32_t nvh_comm_error(nvh_comm* c) {
+    if (!c) return 0;
+    uint32_t f = 0;
+    hipError_t e = hipMemcpy(&f, c->dev.fault, sizeof(f), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        nvh_set_error("nvh_comm_error: %s", hipGetErrorString(e));
+        return NVH_ELAUNCH;
+    }
+    if (f) nvh_set_error("tensor-parallel exchange timed out: rank %d waited 20 s for rank %u", c->dev.rank, f - 1);
+    return (int32_t)f;
+}
+
+extern "C" int32_t nvh_comm_destroy(nvh_comm* c) {
+    if (!c) return NVH_OK;
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < c->dev.world; ++r)
+        if (c->peer_base[r]) (void)hipIpcCloseMemHandle(c->peer_base[r]);
+    (void)hipFree(c->region);
+    (void)hipFree(c->local);
+    delete c;
+    return NVH_OK;
+}

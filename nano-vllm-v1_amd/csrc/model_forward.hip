@@ -1,6 +1,8 @@
 // Native step executor: enqueues every kernel of a Qwen3 forward pass from one call, so the host
 // cost of a step is ~250 HIP launches instead of ~250 Python -> ctypes round trips.  It calls the
 // same entry points a caller would call one by one (identical kernels, order and rounding).
+// Under tensor parallelism (model->comm set) every rank runs it on its shard; the row-parallel GEMMs
+// write into the exchange staging area and one all-reduce kernel per projection follows.
 #include "common.h"
 #include <cstdlib>
 
@@ -76,9 +78,17 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
     const int64_t h = md->hidden, d = md->head_dim, hq = md->num_q_heads, hkv = md->num_kv_heads;
     const int64_t qsz = hq * d, kvsz = hkv * d, qkv_n = qsz + 2 * kvsz;
     const float scale = 1.0f / sqrtf((float)d);
-    const int32_t so = split_for(t, h, qsz), sd = split_for(t, h, md->inter);
+    // partial sums of different ranks meet in bf16: no split-K slab hand-off under tensor parallelism
+    const int32_t so = md->comm ? 1 : split_for(t, h, qsz), sd = md->comm ? 1 : split_for(t, h, md->inter);
 
-    FWD(nvh_embedding(st->input_ids, md->embed, w.residual, t, h, 0, md->vocab_rows, stream));
+    nvh_comm* comm = md->comm;
+    bf16* proj_out = w.y;               // where the row-parallel projections write their bf16 result
+    if (comm) {
+        NVH_REQUIRE(t * h * 2 <= nvh_comm_max_bytes(comm), NVH_EINVAL, "nvh_qwen3_forward: %ld tokens exceed the exchange staging area", (long)t);
+        proj_out = (bf16*)nvh_comm_buffer(comm);   // partial sums are produced straight into the exported area
+    }
+    FWD(nvh_embedding(st->input_ids, md->embed, w.residual, t, h, md->vocab_start, md->vocab_rows, stream));
+    if (comm) FWD(nvh_allreduce_bf16(comm, w.residual, w.residual, t * h, stream));
     bool pending_slabs = false;         // the previous projection left split-K slabs in w.slabs
     int32_t pending_count = 0;
     bf16* pending_y = nullptr;          // or a reduced bf16 result
@@ -121,7 +131,8 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
             FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, nullptr, h, t, h, qsz, so, w.slabs, stream));
             FWD(nvh_add_rmsnorm(nullptr, w.residual, md->post_norm[l], w.x, t, h, md->eps, w.slabs, so, stream));
         } else {
-            FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, w.y, h, t, h, qsz, 1, nullptr, stream));
+            FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, proj_out, h, t, h, qsz, 1, nullptr, stream));
+            if (comm) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
             FWD(nvh_add_rmsnorm(w.y, w.residual, md->post_norm[l], w.x, t, h, md->eps, nullptr, 0, stream));
         }
         // ---- MLP
@@ -137,7 +148,8 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
             pending_count = sd;
             pending_y = nullptr;
         } else {
-            FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, w.y, h, t, h, md->inter, 1, nullptr, stream));
+            FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, proj_out, h, t, h, md->inter, 1, nullptr, stream));
+            if (comm) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
             pending_slabs = false;
             pending_count = 0;
             pending_y = w.y;
@@ -151,13 +163,21 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
 extern "C" int32_t nvh_qwen3_logits(const nvh_qwen3_model* md, const void* hidden, const int32_t* cu_seqlens_q,
                                     const int32_t* need, int64_t num_rows, void* rows_ws, void* logits,
                                     nvh_stream_t stream) {
-    NVH_REQUIRE(md && hidden && logits, NVH_EINVAL, "nvh_qwen3_logits: null pointer");
+    NVH_REQUIRE(md && hidden && (logits || md->comm), NVH_EINVAL, "nvh_qwen3_logits: null pointer");
     if (num_rows == 0) return NVH_OK;
     const void* rows = hidden;
     if (cu_seqlens_q) {
         NVH_REQUIRE(rows_ws, NVH_EINVAL, "nvh_qwen3_logits: rows_ws missing");
         FWD(nvh_gather_last_rows(hidden, cu_seqlens_q, need, rows_ws, num_rows, md->hidden, stream));
         rows = rows_ws;
+    }
+    if (md->comm) {
+        NVH_REQUIRE(num_rows * md->vocab_rows * 2 <= nvh_comm_max_bytes(md->comm), NVH_EINVAL,
+                    "nvh_qwen3_logits: %ld rows of vocabulary shard exceed the exchange staging area", (long)num_rows);
+        void* shard = nvh_comm_buffer(md->comm);
+        FWD(nvh_gemm_bf16_nt(rows, md->hidden, md->lm_head, nullptr, shard, md->vocab_rows, num_rows, md->vocab_rows,
+                             md->hidden, 1, nullptr, stream));
+        return nvh_gather_cols_bf16(md->comm, shard, logits, num_rows, md->vocab_rows, 0, stream);
     }
     return nvh_gemm_bf16_nt(rows, md->hidden, md->lm_head, nullptr, logits, md->vocab_rows, num_rows, md->vocab_rows,
                             md->hidden, 1, nullptr, stream);

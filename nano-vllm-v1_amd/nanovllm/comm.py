@@ -1,0 +1,150 @@
+"""Tensor-parallel all-reduce over xGMI peer mappings (csrc/comm.hip), with torch.distributed as the
+control plane and as the fallback.
+
+The reference sums row-parallel partial outputs with `dist.all_reduce` (NCCL ring; layers/linear.py:407-409,
+layers/embed_head.py:128-129).  Here every rank exports one staging region through HIP IPC and a single
+kernel per rank sums all peers' regions in rank order; the process group is only used to swap the IPC
+handles at start-up and to cross-check the first result.  `all_reduce()` below is what the layers call:
+it uses the peer path when one is installed and the message fits, `dist.all_reduce` otherwise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+from . import _hip
+
+_ACTIVE: "XgmiComm | None" = None
+
+
+class XgmiComm:
+    def __init__(self, rank: int, world: int, max_bytes: int, group=None):
+        lib = _hip.lib()
+        self.rank, self.world, self.group = rank, world, group
+        self.max_bytes = (int(max_bytes) + 15) // 16 * 16
+        handle = ctypes.c_void_p()
+        _hip.check(lib.nvh_comm_create(rank, world, self.max_bytes, ctypes.byref(handle)), "nvh_comm_create")
+        self._h = handle
+        n = lib.nvh_comm_handle_bytes()
+        mine = ctypes.create_string_buffer(n)
+        _hip.check(lib.nvh_comm_get_handle(self._h, mine), "nvh_comm_get_handle")
+        gathered: list = [None] * world
+        dist.all_gather_object(gathered, mine.raw, group=group)
+        _hip.check(lib.nvh_comm_open_peers(self._h, b"".join(gathered)), "nvh_comm_open_peers")
+        dist.barrier(group=group)
+        self.buffer_ptr = int(lib.nvh_comm_buffer(self._h))
+
+    def buffer(self, numel: int) -> torch.Tensor:
+        """bf16 view of the first `numel` elements of this rank's staging area: a producer that writes its
+        partial result here saves the staging copy (then pass the view itself to all_reduce with a separate out)."""
+        assert 0 < numel * 2 <= self.max_bytes
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (numel,), "typestr": "<u2", "data": (self.buffer_ptr, False), "version": 3}
+
+        return torch.as_tensor(_Raw(), device="cuda").view(torch.bfloat16)
+
+    @property
+    def handle(self) -> int:
+        return self._h.value
+
+    def all_reduce(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Sum of x over the ranks.  x: contiguous bf16, numel % 8 == 0.  Returns `out` (default: x itself)."""
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
+        out = x if out is None else out
+        _hip.call("nvh_allreduce_bf16", self._h, x.data_ptr(), out.data_ptr(), x.numel(),
+                  torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def gather_cols(self, x: torch.Tensor, root: int = 0) -> torch.Tensor | None:
+        """x [rows, cols] per rank -> [rows, world*cols] on `root` (rank order along the columns), None elsewhere."""
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 2
+        rows, cols = x.shape
+        out = torch.empty(rows, self.world * cols, dtype=x.dtype, device=x.device) if self.rank == root else None
+        _hip.call("nvh_gather_cols_bf16", self._h, x.data_ptr(), out.data_ptr() if out is not None else 0, rows, cols, root,
+                  torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def fits(self, x: torch.Tensor) -> bool:
+        return x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() % 8 == 0 and x.numel() * 2 <= self.max_bytes
+
+    def check(self) -> None:
+        """Synchronises; raises if an exchange timed out waiting for a peer."""
+        rc = _hip.lib().nvh_comm_error(self._h)
+        if rc:
+            raise _hip.HipError(_hip.lib().nvh_last_error().decode())
+
+    def self_test(self, sizes=(8, 1 << 12, 1 << 18, 3 << 18)) -> bool:
+        """Compare against torch.distributed on a few message sizes (one- and two-shot); identical on every rank."""
+        ok = True
+        for i, n in enumerate(sizes):
+            if n * 2 > self.max_bytes:
+                continue
+            g = torch.Generator(device="cpu").manual_seed(1234 + 17 * i + self.rank)
+            x = torch.randn(n, generator=g, dtype=torch.float32).to(torch.bfloat16).cuda()
+            ref = x.float()
+            dist.all_reduce(ref, group=self.group)
+            try:
+                got = self.all_reduce(x.clone())
+                self.check()
+            except _hip.HipError as e:               # a peer never answered: report, let every rank agree below
+                print(f"[nanovllm] rank {self.rank}: {e}", file=sys.stderr)
+                ok = False
+                break
+            ok = ok and bool(torch.allclose(got.float(), ref, atol=0.0, rtol=2.0 ** -7))
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item())
+
+    def close(self) -> None:
+        if self._h is not None:
+            _hip.lib().nvh_comm_destroy(self._h)
+            self._h = None
+
+
+def install(rank: int, world: int, max_bytes: int, group=None) -> "XgmiComm | None":
+    """Create the peer path for this process, verify it, make it the one `all_reduce` uses.  Returns None
+    (and says so on stderr) when NANOVLLM_XGMI_AR=0 or the verification fails; callers then run on RCCL."""
+    global _ACTIVE
+    if os.environ.get("NANOVLLM_XGMI_AR", "1") == "0":
+        return None
+    comm = XgmiComm(rank, world, max_bytes, group)
+    if not comm.self_test():
+        print(f"[nanovllm] rank {rank}: xGMI all-reduce self-test FAILED; using torch.distributed", file=sys.stderr)
+        comm.close()
+        return None
+    _ACTIVE = comm
+    return comm
+
+
+def uninstall() -> None:
+    global _ACTIVE
+    if _ACTIVE is not None:
+        _ACTIVE.close()
+        _ACTIVE = None
+
+
+def active() -> "XgmiComm | None":
+    return _ACTIVE
+
+
+def gather_cols(x: torch.Tensor, root: int = 0) -> torch.Tensor | None:
+    """Vocabulary shards [rows, cols] of every rank -> [rows, world*cols] on `root`, None on the other ranks."""
+    if _ACTIVE is not None and _ACTIVE.fits(x) and x.shape[-1] % 8 == 0:
+        return _ACTIVE.gather_cols(x, root)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = [torch.empty_like(x) for _ in range(world)] if rank == root else None
+    dist.gather(x, parts, root)
+    return torch.cat(parts, -1) if rank == root else None
+
+
+def all_reduce(y: torch.Tensor) -> torch.Tensor:
+    """In-place sum over the tensor-parallel ranks."""
+    if _ACTIVE is not None and _ACTIVE.fits(y):
+        return _ACTIVE.all_reduce(y)
+    dist.all_reduce(y)
+    return y

@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .. import _hip
+from .. import _hip, comm
 from ..config import Config, model_dtype
 from ..layers.sampler import Sampler
 from ..models.qwen3 import Qwen3ForCausalLM
@@ -142,6 +142,13 @@ class ModelRunner:
         self.device = torch.device("cuda", device_index)
         _hip.check(_hip.lib().nvh_device_check(device_index), "nvh_device_check")
 
+        self.comm = None
+        if self.world_size > 1:
+            # staging: the widest all-reduce (a full token budget of hidden rows) or logits gather (every sequence)
+            vocab_shard = hf.vocab_size // self.world_size
+            nbytes = 2 * max(config.max_num_batched_tokens * hf.hidden_size, config.max_num_seqs * vocab_shard)
+            self.comm = comm.install(rank, self.world_size, nbytes)
+
         dtype = model_dtype(hf)
         if dtype != torch.bfloat16:
             raise _hip.HipError(f"model dtype {dtype} unsupported: the kernel path is bf16 only")
@@ -157,11 +164,12 @@ class ModelRunner:
             self.sampler = Sampler()
             self.staging = _Staging(self.device)
             self.graphs, self.graph_bs = {}, []
-            # one native call per step on a single rank; the operator modules (with RCCL between
-            # them) otherwise.  NANOVLLM_NATIVE=0 forces the module path (parity tests use it).
-            use_native = self.world_size == 1 and os.environ.get("NANOVLLM_NATIVE", "1") != "0" \
+            # one native call per step (per rank; ranks meet through the xGMI exchange); the operator modules,
+            # with torch.distributed collectives between them when the exchange is unavailable, otherwise.
+            # NANOVLLM_NATIVE=0 forces the module path (parity tests use it).
+            use_native = (self.world_size == 1 or self.comm is not None) and os.environ.get("NANOVLLM_NATIVE", "1") != "0" \
                 and not getattr(hf, "attention_bias", True)
-            self.native = NativeQwen3(self.model) if use_native else None
+            self.native = NativeQwen3(self.model, comm=self.comm) if use_native else None
             self.warmup_model()
             self.allocate_kv_cache()
             if self.native is not None:
@@ -204,6 +212,11 @@ class ModelRunner:
                 self.shm.unlink()
         self.graphs = {}
         torch.cuda.synchronize()
+        if self.comm is not None:
+            if dist.is_initialized():
+                dist.barrier()                  # no rank unmaps a region a peer's kernel may still read
+            comm.uninstall()
+            self.comm = None
         if dist.is_initialized() and not self.external_group:
             dist.destroy_process_group()
 

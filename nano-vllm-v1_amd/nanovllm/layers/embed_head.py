@@ -7,10 +7,9 @@ the context's need list; an empty list selects every sequence), then vocab shard
 on rank 0.  Kernels: nvh_embedding, nvh_gather_last_rows (csrc/elementwise.hip), nvh_gemm_bf16_nt.
 """
 import torch
-import torch.distributed as dist
 from torch import nn
 
-from .. import ops
+from .. import comm, ops
 from ..utils.context import get_context
 from .linear import tp_rank, tp_world
 
@@ -34,7 +33,7 @@ class VocabParallelEmbedding(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = ops.embedding(x, self.weight.data, self.vocab_start_idx)
         if self.tp_size > 1:
-            dist.all_reduce(y)
+            y = comm.all_reduce(y)
         return y
 
 
@@ -56,7 +55,5 @@ class ParallelLMHead(VocabParallelEmbedding):
         """Logits of already selected hidden rows [B', H] (one-token-per-sequence steps skip the gather)."""
         logits = ops.linear(rows, self.weight.data)
         if self.tp_size > 1:
-            parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
-            dist.gather(logits, parts, 0)
-            logits = torch.cat(parts, -1) if self.tp_rank == 0 else None
+            logits = comm.gather_cols(logits, 0)
         return logits

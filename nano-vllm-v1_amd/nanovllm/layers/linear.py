@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from .. import ops
+from .. import comm, ops
 
 
 class SplitKOutput:
@@ -143,5 +143,5 @@ class RowParallelLinear(LinearBase):
                 return SplitKOutput(ops.linear_splitk(x, self.weight.data, split_k))
         y = ops.linear(x, self.weight.data, self._bias() if self.tp_rank == 0 else None)
         if self.tp_size > 1:
-            dist.all_reduce(y)
+            y = comm.all_reduce(y)
         return y

@@ -2,8 +2,8 @@
 `nvh_qwen3_model` descriptor from a Qwen3ForCausalLM module once, and runs one step per call.
 
 The descriptor holds raw device pointers into the module's parameters and KV-cache views; the
-module keeps owning them.  Single rank only (tensor-parallel runs go through the operator modules,
-which all-reduce between kernels)."""
+module keeps owning them.  With an `XgmiComm` the same executor runs one tensor-parallel rank: the
+descriptor then holds the rank's shard sizes and the exchange handle."""
 from __future__ import annotations
 
 import ctypes as C
@@ -20,10 +20,10 @@ MODE_PACKED, MODE_PAGED, MODE_DECODE = 0, 1, 2
 
 class ModelDesc(C.Structure):
     _fields_ = [("hidden", i32), ("layers", i32), ("num_q_heads", i32), ("num_kv_heads", i32), ("head_dim", i32),
-                ("inter", i32), ("vocab_rows", i32), ("reserved", i32), ("eps", f32), ("reserved2", i32),
+                ("inter", i32), ("vocab_rows", i32), ("vocab_start", i32), ("eps", f32), ("reserved2", i32),
                 ("max_position", i64), ("embed", vp), ("final_norm", vp), ("lm_head", vp), ("cos_sin", vp),
                 ("qkv_w", PP), ("o_w", PP), ("q_norm", PP), ("k_norm", PP), ("gate_up_w", PP), ("gate_up_inter", PP), ("down_w", PP),
-                ("input_norm", PP), ("post_norm", PP), ("k_cache", PP), ("v_cache", PP)]
+                ("input_norm", PP), ("post_norm", PP), ("k_cache", PP), ("v_cache", PP), ("comm", vp)]
 
 
 class StepDesc(C.Structure):
@@ -37,9 +37,10 @@ def _ptr(t):
 
 
 class NativeQwen3:
-    def __init__(self, model, fuse_swiglu: bool = True):
+    def __init__(self, model, fuse_swiglu: bool = True, comm=None):
         self.lib = _hip.lib()
         self.model = model
+        self.comm = comm
         self.fuse_swiglu = fuse_swiglu
         self.rebuild()
 
@@ -62,6 +63,8 @@ class NativeQwen3:
         d.num_q_heads, d.num_kv_heads, d.head_dim = a0.num_heads, a0.num_kv_heads, a0.head_dim
         d.inter = layers[0].mlp.down_proj.weight.shape[1]
         d.vocab_rows = m.lm_head.weight.shape[0]
+        d.vocab_start = m.lm_head.vocab_start_idx
+        d.comm = self.comm.handle if self.comm is not None else None
         d.eps = layers[0].input_layernorm.eps
         table = a0.rotary_emb.table2d()
         self._keep = [table]
@@ -112,9 +115,14 @@ class NativeQwen3:
         """lm_head over the last scheduled row of the selected sequences (cu_seqlens_q None: `hidden`
         rows are used directly)."""
         n = hidden.shape[0] if cu_seqlens_q is None else num_rows
-        out = torch.empty(n, self.desc.vocab_rows, dtype=torch.bfloat16, device=self.device)
+        if self.comm is None:
+            out = torch.empty(n, self.desc.vocab_rows, dtype=torch.bfloat16, device=self.device)
+        elif self.comm.rank == 0:
+            out = torch.empty(n, self.comm.world * self.desc.vocab_rows, dtype=torch.bfloat16, device=self.device)
+        else:
+            out = None
         rows = torch.empty(n, self.desc.hidden, dtype=torch.bfloat16, device=self.device) if cu_seqlens_q is not None else None
         _hip.check(self.lib.nvh_qwen3_logits(C.byref(self.desc), hidden.data_ptr(), _ptr(cu_seqlens_q), _ptr(need), n,
-                                             _ptr(rows), out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                                             _ptr(rows), _ptr(out), torch.cuda.current_stream().cuda_stream),
                    "nvh_qwen3_logits")
         return out

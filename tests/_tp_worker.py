@@ -1,0 +1,84 @@
+"""Worker of tests/test_tp_gpu.py: one tensor-parallel rank of the tiny model.  All ranks share cuda:0 (one-GPU
+test box); gloo on 127.0.0.1 is the control plane, the xGMI exchange carries the data.  Rank 0 checks the
+logits of a prefill + decode run against the single-rank oracle."""
+import os
+import sys
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "nano-vllm-v1_amd"))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+    rank, world, port, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    os.environ["LOCAL_RANK"] = "0"
+    os.environ["NANOVLLM_NATIVE"] = "0" if mode == "modules" else "1"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    from conftest import TINY
+    from test_model_gpu import TINY_DIR, hf_named, seq
+    from oracle import ref_model as M
+    from nanovllm import comm
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+
+    cfg = Config(TINY_DIR, max_num_batched_tokens=1024, max_num_seqs=8, max_model_len=2048, tensor_parallel_size=world,
+                 enforce_eager=(mode != "graph"), num_kvcache_blocks=12, chunked_prefill=True)
+    runner = ModelRunner(cfg, rank, [])
+    assert comm.active() is not None, "xGMI exchange not installed"
+    assert (runner.native is not None) == (mode != "modules")
+    shape = M.ModelShape(**TINY)
+    weights = M.random_weights(shape, seed=0, std=0.05)
+    runner.load_weights(hf_named(weights, shape))
+    oracle = M.RefRunner(shape, weights, 12) if rank == 0 else None
+
+    g = torch.Generator().manual_seed(31)
+    prompts = [torch.randint(0, 1024, (n,), generator=g).tolist() for n in (5, 300, 257)]
+    tables = [[0], [1, 2], [3, 4]]
+    seqs = [seq(p, 0, len(p), t) for p, t in zip(prompts, tables)]
+    states = [M.SeqState(list(p), 0, len(p), list(t)) for p, t in zip(prompts, tables)]
+    worst = 0.0
+    for step in range(5):
+        logits, _, need = runner.forward_logits(seqs)
+        assert need.tolist() == [0, 1, 2]
+        if rank == 0:
+            ref, _ = oracle.run(states)
+            got = logits.float().cpu()
+            err = (got - ref.float()).abs()
+            worst = max(worst, float(err.max()))
+            assert bool((err <= 3e-2 + 2e-2 * ref.float().abs()).all()), f"step {step}: max err {float(err.max()):.4g}"
+            assert torch.equal(got.argmax(-1), ref.float().argmax(-1)), f"step {step}: greedy ids differ"
+            toks = got.argmax(-1)
+        else:
+            assert logits is None
+            toks = torch.zeros(3, dtype=torch.int64)
+        dist.broadcast(toks, 0)
+        for i, (s, st, t) in enumerate(zip(seqs, states, toks.tolist())):
+            s.num_cached_tokens += s.num_new_tokens
+            s.append_token(t)
+            s.num_new_tokens = 1
+            s.block_table = tables[i][:(len(s) + 255) // 256]
+            st.token_ids.append(t)
+            st.num_cached_tokens, st.num_new_tokens = s.num_cached_tokens, 1
+            st.block_table = list(s.block_table)
+    if mode == "graph":
+        assert runner.graphs
+    runner.comm.check()
+    if rank == 0:
+        tok, need = runner.run(seqs)                 # sampler on rank 0 only
+        assert len(tok) == 3
+        print(f"max |logit err| vs oracle over 5 steps: {worst:.4g}")
+    else:
+        tok, need = runner.run(seqs)
+        assert tok is None
+    runner.exit()
+    dist.destroy_process_group()
+    print(f"rank {rank} OK")
+
+
+if __name__ == "__main__":
+    main()
