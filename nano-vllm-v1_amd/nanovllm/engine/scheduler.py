@@ -1,0 +1,117 @@
+"""Step scheduler in the v1 style (behaviour of the reference's engine/scheduler.py:58-267): running
+sequences first, LIFO pre-emption when pages run out, then admission from the waiting queue - all under one
+token budget per step, with optional chunking of long prefills.
+
+What the runner sees of a scheduled sequence is (num_cached_tokens, num_new_tokens, block_table); decode is
+simply num_new_tokens == 1.  `schedule()` returns the list (running sequences first, newly admitted after);
+`postprocess()` consumes the sampled ids, which exist only for the sequences whose scheduled tokens reach the
+end of what they hold (`seq_need_compute_logits` indexes into the scheduled list).
+"""
+from __future__ import annotations
+
+from collections import deque
+
+from ..config import Config
+from .block_manager import BlockManager
+from .sequence import Sequence, SequenceStatus
+
+
+class Scheduler:
+    def __init__(self, config: Config):
+        self.enable_chunked = config.chunked_prefill
+        self.max_model_len = config.max_model_len
+        self.max_num_seqs = config.max_num_seqs
+        self.max_num_batched_tokens = config.max_num_batched_tokens
+        self.eos = config.eos
+        self.block_manager = BlockManager(config.num_kvcache_blocks, config.kvcache_block_size)
+        self.waiting: deque[Sequence] = deque()
+        self.running: deque[Sequence] = deque()
+
+    def is_finished(self) -> bool:
+        return not self.waiting and not self.running
+
+    def add(self, seq: Sequence):
+        assert len(seq) <= self.max_model_len - 1, "Sequence length exceeds max_model_len"
+        self.waiting.append(seq)
+
+    # ------------------------------------------------------------------ one step
+    def schedule(self) -> list[Sequence]:
+        budget = self.max_num_batched_tokens
+        continued, budget, preempted = self._continue_running(budget)
+        admitted = [] if preempted else self._admit_waiting(budget)
+        scheduled = continued + admitted
+        assert scheduled, "nothing could be scheduled"
+        return scheduled
+
+    def _continue_running(self, budget: int):
+        """Running sequences in queue order.  When pages run out the NEWEST running sequence is pre-empted
+        (possibly the one being considered, which ends the pass)."""
+        bm = self.block_manager
+        scheduled: list[Sequence] = []
+        preempted = False
+        i = 0
+        while i < len(self.running) and budget > 0:
+            seq = self.running[i]
+            n = len(seq) - seq.num_cached_tokens
+            if self.enable_chunked:
+                n = min(n, budget)
+            n = min(n, self.max_model_len - 1 - seq.num_cached_tokens)
+            assert n > 0
+            while not bm.can_append(seq, n) and len(self.running) > i:
+                self.preempt(self.running.pop())
+                preempted = True
+            if len(self.running) == i:                       # seq itself was the victim
+                break
+            seq.num_new_tokens = n
+            bm.may_append(seq)
+            scheduled.append(seq)
+            budget -= n
+            i += 1
+        return scheduled, budget, preempted
+
+    def _admit_waiting(self, budget: int) -> list[Sequence]:
+        """Head-of-line admission while tokens, pages and sequence slots last.  Pre-emption in this step
+        disables admission (the caller checks), or the freed pages would be taken straight back."""
+        bm = self.block_manager
+        admitted: list[Sequence] = []
+        while self.waiting and budget > 0 and len(self.running) < self.max_num_seqs:
+            seq = self.waiting[0]
+            assert not seq.block_table
+            hit_used, hit_free, n = bm.get_token_layout(seq)
+            if self.enable_chunked:
+                n = min(n, budget)
+            assert n > 0
+            if n > budget or not bm.can_allocate(hit_free + n):
+                break
+            seq.num_new_tokens = n
+            bm.allocate(seq)
+            assert seq.num_cached_tokens == hit_used + hit_free
+            budget -= n
+            seq.status = SequenceStatus.RUNNING
+            self.waiting.popleft()
+            self.running.append(seq)
+            admitted.append(seq)
+        return admitted
+
+    def preempt(self, seq: Sequence):
+        """Drop the sequence's pages and put it at the head of the waiting queue; it is recomputed (or finds its
+        pages through the prefix hashes) when it is admitted again."""
+        seq.status = SequenceStatus.WAITING
+        self.block_manager.deallocate(seq)
+        self.waiting.appendleft(seq)
+
+    def postprocess(self, seqs: list[Sequence], token_ids: list[int], seq_need_compute_logits) -> None:
+        need = [int(i) for i in seq_need_compute_logits]
+        assert len(token_ids) == len(need)
+        for index, token_id in zip(need, token_ids):
+            seq = seqs[index]
+            seq.append_token(token_id)
+            hit_eos = not seq.ignore_eos and token_id == self.eos
+            if hit_eos or seq.num_completion_tokens == seq.max_tokens or len(seq) >= self.max_model_len:
+                seq.status = SequenceStatus.FINISHED
+                self.block_manager.deallocate(seq)
+                self.running.remove(seq)
+        for seq in seqs:
+            if seq.status != SequenceStatus.FINISHED:
+                seq.num_cached_tokens += seq.num_new_tokens
+                seq.num_new_tokens = 0

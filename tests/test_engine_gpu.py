@@ -1,0 +1,125 @@
+"""LLM front-end end to end on the GPU: scheduler + page manager + runner + sampler through `LLM.generate`,
+checked against the CPU oracle by teacher forcing (every generated id must be the oracle's argmax at its
+position, up to the logit tolerance of the kernel path - exact ties in bf16 may resolve either way)."""
+import pytest
+import torch
+
+from conftest import TINY
+from test_model_gpu import TINY_DIR, hf_named
+
+from oracle import ref_model as M
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def weights():
+    shape = M.ModelShape(**TINY)
+    return shape, M.random_weights(shape, seed=0, std=0.05)
+
+
+def make_llm(weights, **kw):
+    from nanovllm import LLM
+    shape, w = weights
+    cfg = dict(max_num_batched_tokens=512, max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=24,
+               chunked_prefill=True, enforce_eager=False)
+    cfg.update(kw)
+    llm = LLM(TINY_DIR, **cfg)
+    llm.model_runner.load_weights(hf_named(w, shape))
+    return llm
+
+
+def check_teacher_forced(weights, prompt, completion, atol=3e-2, rtol=2e-2):
+    """Oracle forward over prompt + completion in one packed pass; returns the number of exact argmax matches."""
+    shape, w = weights
+    oracle = M.RefRunner(shape, w, 0)
+    toks = list(prompt) + list(completion[:-1])
+    s = M.SeqState(toks, 0, len(toks), [])
+    inp = M.prepare_model_input([s])
+    hidden = oracle.forward(inp)
+    logits = R.linear(hidden[len(prompt) - 1:], w["lm_head.weight"]).float()
+    assert logits.shape[0] == len(completion)
+    exact = 0
+    for row, tok in zip(logits, completion):
+        top = float(row.max())
+        assert float(row[tok]) >= top - (atol + rtol * abs(top)), f"token {tok}: logit {float(row[tok]):.4f} vs max {top:.4f}"
+        exact += int(int(row.argmax()) == tok)
+    return exact
+
+
+def prompts_of(lengths, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 1024, (n,), generator=g).tolist() for n in lengths]
+
+
+def test_generate_mixed_lengths_chunked(weights):
+    from nanovllm import SamplingParams
+    llm = make_llm(weights, max_num_batched_tokens=200)       # forces chunking and mixed prefill+decode steps
+    try:
+        prompts = prompts_of([5, 300, 257, 64, 700], seed=3)
+        sps = [SamplingParams(temperature=1e-9, max_tokens=n, ignore_eos=True) for n in (6, 4, 9, 3, 5)]
+        outs = llm.generate(prompts, sps, use_tqdm=False)
+        assert [len(o["token_ids"]) for o in outs] == [6, 4, 9, 3, 5] and all(o["text"] == "" for o in outs)
+        exact = sum(check_teacher_forced(weights, p, o["token_ids"]) for p, o in zip(prompts, outs))
+        assert exact >= 26                                     # 27 generated ids; at most one bf16 tie
+        assert llm.is_finished() and not llm.scheduler.block_manager.used_block_ids
+    finally:
+        llm.exit()
+
+
+def test_generate_prefix_reuse_and_preemption(weights):
+    from nanovllm import SamplingParams
+    llm = make_llm(weights, num_kvcache_blocks=4, max_num_batched_tokens=1024)
+    try:
+        shared = prompts_of([520], seed=4)[0]
+        tails = prompts_of([10, 20, 250], seed=5)
+        prompts = [shared + tails[0], shared[:512] + tails[1], tails[2]]
+        sp = SamplingParams(temperature=1e-9, max_tokens=12, ignore_eos=True)
+        # first request alone, so its two full pages are hashed before the second one arrives
+        first = llm.generate(prompts[:1], sp, use_tqdm=False)
+        bm = llm.scheduler.block_manager
+        llm.add_request(prompts[1], sp)
+        assert bm.get_token_layout(llm.scheduler.waiting[0]) == (0, 512, 20)     # prefix found in released pages
+        llm.add_request(prompts[2], sp)
+        done = {}
+        preempted = False
+        while not llm.is_finished():
+            before = len(llm.scheduler.waiting)
+            outs, _ = llm.step()
+            preempted = preempted or len(llm.scheduler.waiting) > before
+            done.update(dict(outs))
+        rest = [done[k] for k in sorted(done)]
+        assert preempted, "4 pages must not be enough for both sequences to finish without pre-emption"
+        for p, ids in zip(prompts, [first[0]["token_ids"]] + rest):
+            assert len(ids) == 12
+            check_teacher_forced(weights, p, ids)
+    finally:
+        llm.exit()
+
+
+def test_step_without_finished_prompt_returns_no_tokens(weights):
+    """A lone long prompt under chunked prefill: the first chunks produce no token and must not break the loop."""
+    from nanovllm import SamplingParams
+    llm = make_llm(weights, max_num_batched_tokens=128)
+    try:
+        prompt = prompts_of([600], seed=6)[0]
+        out = llm.generate([prompt], SamplingParams(temperature=1e-9, max_tokens=3, ignore_eos=True), use_tqdm=False)
+        check_teacher_forced(weights, prompt, out[0]["token_ids"])
+    finally:
+        llm.exit()
+
+
+def test_serving_harness_accounts_every_request(weights):
+    """Poisson-arrival harness on the tiny model: all requests complete, token accounting and metric definitions."""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import serving_bench as sb
+    r = sb.main(["--model", TINY_DIR, "--num-requests", "24", "--request-rate", "400", "--max-num-batched-tokens", "256",
+                 "--max-num-seqs", "16", "--max-model-len", "2048", "--random-input-len", "40", "--random-output-len", "7",
+                 "--chunked-prefill", "--num-kvcache-blocks", "32", "--warmup-requests", "4"])
+    assert r["completed"] == r["requests"] == 24
+    assert r["input_tokens"] == 24 * 40 and r["output_tokens"] == 24 * 7
+    assert r["mean_ttft_ms"] > 0 and r["mean_tpot_ms"] > 0 and r["mean_latency_s"] * 1e3 >= r["mean_ttft_ms"]
+    assert abs(r["throughput_tok_s"] - (24 * 47) / r["total_time_s"]) < 1e-6
