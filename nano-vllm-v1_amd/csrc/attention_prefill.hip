@@ -13,16 +13,57 @@
 //         tile ARE the B fragment of k-step s of the next product (no lane movement);
 //   O^T += V^T . P^T A = V^T read straight from the row-major V tile with the transposing
 //                    LDS read (ds_read_b64_tr_b16), k order matched to the P fragment.
-// K/V tiles go global -> LDS by 16-byte LDS-DMA (two LDS stages, one barrier per tile): the DMA of
-// tile t+1 runs under the MFMA work of tile t; the swizzles are applied to the per-lane SOURCE
-// address because the DMA writes lane-linear.  Two workgroups fit a CU (<= 256 registers, 64 KB
-// LDS), so one's softmax overlaps the other's MFMAs.
+// K/V tiles go global -> LDS by 16-byte LDS-DMA into a ring of LDS stages (2 in use; 4 measured no faster), one
+// barrier per tile and a counted vmcnt wait: the DMA of tile t+1 runs under the MFMA work of tile t; the
+// swizzles are applied to the per-lane SOURCE address because the DMA writes lane-linear.  Two workgroups fit a
+// CU (<= 256 registers, 64 KB LDS), so one's softmax overlaps the other's MFMAs.  Nothing in the tile loop may
+// make the compiler wait for vmcnt(0) (that drains the prefetch): Q fragments are pinned in registers before
+// the loop, the transposing V reads are issued from inline asm, and the loop must stay free of register spills.
 // Long key ranges can be cut into `num_splits` ranges of whole tiles (gridDim.z = B * splits):
 // each range leaves an unnormalised fp32 partial + (max, sum) and the decode path's combine
 // kernel merges them - this is what fills the chip when a chunk has few query blocks.
 #include "common.h"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
+
+#ifdef NVH_ATTN_PROF
+// Tuning aid (never defined in the shipped library): per-phase cycle totals of wave 0 of every workgroup.
+__device__ unsigned long long g_attn_prof[8];
+extern "C" int32_t nvh_debug_attn_prof(unsigned long long* out, int32_t reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_prof), sizeof(g_attn_prof)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define PROF_DECL unsigned long long prof_acc[5] = {0, 0, 0, 0, 0}
+#define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PROF_ADD(slot, a, b) prof_acc[slot] += (b) - (a)
+#define PROF_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_attn_prof[i_], prof_acc[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF_T(var)
+#define PROF_ADD(slot, a, b)
+#define PROF_FLUSH
+#endif
+
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
+}
+// Wait until at most `ahead` (<= MAXAHEAD) tiles of PW DMA instructions each are still in flight for this wave.
+template <int PW, int MAXAHEAD>
+__device__ __forceinline__ void attn_wait_tiles(int ahead) {
+    if constexpr (MAXAHEAD == 0) {
+        attn_wait_vmcnt<0>();
+    } else {
+        if (ahead >= MAXAHEAD) attn_wait_vmcnt<PW * MAXAHEAD>();
+        else attn_wait_tiles<PW, MAXAHEAD - 1>(ahead);
+    }
+}
 
 __device__ __forceinline__ int v_off(int row, int ch) {          // V tile: 256-B rows, chunk XOR
     return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
@@ -31,8 +72,8 @@ __device__ __forceinline__ int k_off(int row, int ch) {          // K tile
     return 256 * row + 16 * (ch ^ (row & 15));
 }
 
-template <int G, int RB, bool PAGED>
-__global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 ? 2 : 1)) void attn_varlen_kernel(
+template <int G, int RB, int STAGES, bool PAGED>
+__global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 && STAGES == 2 ? 2 : 1)) void attn_varlen_kernel(
     const bf16* __restrict__ q, int64_t q_stride, const bf16* __restrict__ kp, const bf16* __restrict__ vp,
     int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ tables, int64_t table_stride, int hkv, float scale_log2, bf16* __restrict__ out,
@@ -41,7 +82,8 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 ? 2 : 1)) void attn_varle
     constexpr int PIECES = 32;                                   // 1-KiB DMA pieces per K+V tile (4 keys each)
     constexpr int PW = (PIECES + NW - 1) / NW;                   // pieces per wave (uniform; extras duplicate)
     constexpr int STAGE = 2 * 64 * 256;                          // K tile + V tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages
+    static_assert(STAGES == 2 || STAGES == 4, "the stage offset is folded into LDS addresses as a bit field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x (K tile + V tile)
 
     const int b = blockIdx.z / num_splits, split = blockIdx.z % num_splits, kvh = blockIdx.y;
     const int q_beg = cu_q[b], lq = cu_q[b + 1] - q_beg;
@@ -71,74 +113,101 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 ? 2 : 1)) void attn_varle
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    PROF_DECL;
 
     if (kt_beg < kt_end) {
-        // Q^T fragments: lane (q = ql, half hh) holds Q[q][16ks + 8hh .. +7]
-        bf16x8 qf[8];
-        {
-            const bf16* qp = q + (int64_t)(q_beg + qrow) * q_stride + (int64_t)h * 128 + 8 * hh;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
-        }
-        // LDS-DMA staging: piece p < 16 -> K keys 4p..4p+3, p >= 16 -> V keys; lane -> (key, chunk position)
+        bf16x8 qf[8];                                            // Q^T fragments, filled below
+        // LDS-DMA staging: piece p < 16 -> K keys 4p..4p+3, p >= 16 -> V keys; lane -> (key = 4p + l4, chunk position).
+        // The swizzled source chunk is (lane term) ^ (piece term) for both tiles, so three lane registers and a few
+        // wave-uniform values describe every piece; a tile adds one wave-uniform offset.
+        const int l4 = lane >> 4, pos = lane & 15;
+        const int64_t row_stride = PAGED ? (int64_t)hkv * 128 : kv_stride;       // elements between consecutive keys
+        const int dma_row = l4 * (int)row_stride + kvh * 128;                    // lane's key row inside a 4-key piece
+        const int dma_ck = (pos ^ l4) * 8, dma_cv = (pos ^ (l4 << 2)) * 8;       // K: pos ^ (key & 15); V: pos ^ ((key&3)<<2 | (key>>2)&3)
+        // page id of the next tile to stage, fetched one iteration ahead so its scalar-load latency is never exposed
+        const int32_t* table_row = PAGED ? tables + (int64_t)b * table_stride : nullptr;
+        const int last_page = PAGED ? max(lk - 1, 0) >> 8 : 0;
+        int page_ahead = 0;
+        auto fetch_page = [&](int kt) {
+            if constexpr (PAGED) page_ahead = table_row[min(kt >> 2, last_page)];
+        };
         auto stage = [&](int kt) {
-            char* base = smem + (kt & 1) * STAGE;
-            int64_t page_base = 0;
-            if constexpr (PAGED) page_base = (int64_t)tables[(int64_t)b * table_stride + ((kt * 64) >> 8)] * NVH_KV_PAGE;
+            LDS_AS char* base = (LDS_AS char*)smem + (kt & (STAGES - 1)) * STAGE;
+            int64_t tile_off;                                    // wave-uniform element offset of key kt*64
+            if constexpr (PAGED) {
+                const int64_t page = page_ahead;                 // fetch_page(kt) ran an iteration ago
+                fetch_page(kt + 1);
+                tile_off = (page * NVH_KV_PAGE + (kt & 3) * 64) * row_stride;
+            } else {
+                tile_off = (int64_t)(k_beg + kt * 64) * row_stride;
+            }
+            const bool full = kt * 64 + 63 < lk;
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 int p = wave + i * NW;
                 if (p >= PIECES) p -= PIECES;
-                const int isv = p >> 4;
-                const int key = (p & 15) * 4 + (lane >> 4), pos = lane & 15;
-                const int ch = isv ? (pos ^ (((key & 3) << 2) | ((key >> 2) & 3))) : (pos ^ (key & 15));
-                const int kk = min(kt * 64 + key, lk - 1);
-                int64_t row;
-                if constexpr (PAGED) row = ((page_base + (kk & 255)) * hkv + kvh) * 128;
-                else row = (int64_t)(k_beg + kk) * kv_stride + (int64_t)kvh * 128;
-                const bf16* src = (isv ? vp : kp) + row + ch * 8;
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(base + p * 1024), 16, 0, 0);
+                const int isv = p >> 4, pv = p & 15;
+                const bf16* sbase = (isv ? vp : kp) + tile_off + (int64_t)(4 * pv) * row_stride;
+                int off = dma_row + (isv ? (dma_cv ^ (8 * (pv & 3))) : (dma_ck ^ (32 * (pv & 3))));
+                if (!full) {
+                    // last, partly filled tile: keys past the end re-read the last valid key (they are masked anyway)
+                    const int over = max(kt * 64 + 4 * pv + l4 - (lk - 1), 0);
+                    off -= over * (int)row_stride;
+                }
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sbase + off), (LDS_AS void*)(base + p * 1024), 16, 0, 0);
             }
         };
 
-        stage(kt_beg);
-        for (int kt = kt_beg; kt < kt_end; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile kt have landed
-            __builtin_amdgcn_s_barrier();                       // ... everyone's have, and tile kt-1 is consumed
-            asm volatile("" ::: "memory");
-            if (kt + 1 < kt_end) stage(kt + 1);
-            if (kt * 64 > wave_last_key) continue;              // tile entirely above this wave's diagonal
-            const char* sm_k = smem + (kt & 1) * STAGE;
-            const char* sm_v = sm_k + 64 * 256;
+        // LDS read addresses: every fragment read is (lane term ^ wave-uniform term) + (compile-time offset).
+        //   K fragment of k-step ks, key t2*32 + ql:   256*key + 16*((2ks + hh) ^ (key & 15))
+        //   V^T fragment (dt, t2, sft, half):          v_off(row, ch) with the row/chunk split below
+        const int gi = lane >> 4, li = lane & 15;
+        const int tr_q = li >> 2, tr_p = li & 3;
+        // lane parts; the (ks) / (dt, half) parts and the stage bit are wave-uniform XOR terms applied per tile
+        const int kb0 = 256 * ql + ((hh ^ (ql & 15)) << 4);
+        const int vb0 = 256 * (4 * (gi >> 1) + tr_q) + 16 * ((2 * (gi & 1) + (tr_p >> 1)) ^ ((tr_q << 2) | (gi >> 1))) + 8 * (tr_p & 1);
+        LDS_AS const char* lds = (LDS_AS const char*)smem;
 
+        // One 64-key tile.  MASK: the tile crosses this wave's causal diagonal.
+        auto tile = [&](int kt, auto mask_tag) {
+            constexpr bool MASK = decltype(mask_tag)::value;
+            const int soff = (kt & (STAGES - 1)) * STAGE;
+            int kb[8], vb[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kb[ks] = kb0 ^ ((32 * ks) ^ soff);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) vb[dt][half] = vb0 ^ ((16 * ((4 * dt) ^ (2 * half))) ^ soff);
             // ---- S^T = K . Q^T for the two 32-key halves
             f32x16 st[2];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
+                if (t2) __builtin_amdgcn_sched_barrier(0);      // 8 K fragments (32 registers) in flight, not 16
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
-                const int key = t2 * 32 + ql;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
-                    const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(sm_k + k_off(key, 2 * ks + hh));
+                    if (ks == 2 || ks == 4 || ks == 6) __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 kfrag = *reinterpret_cast<LDS_AS const bf16x8*>(lds + kb[ks] + 8192 * t2);
                     st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], st[t2], 0, 0, 0);
                 }
             }
             // ---- causal mask, online softmax (query on the lane).  Scores stay unscaled: the scale is
             // folded into the exponent, p = exp2(s * scale*log2e - m), one FMA per element.
-            const bool need_mask = kt * 64 + 63 > wave_first_row + shift;
-            const int vis = qrow + shift;          // last visible key of this lane's query
+            if constexpr (MASK) {
+                const int vis = qrow + shift - kt * 64 - 4 * hh;   // last visible key, relative to the lane's first
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        st[t2][r] = (t2 * 32 + (r & 3) + 8 * (r >> 2)) > vis ? -INFINITY : st[t2][r];
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (need_mask) {
-                        const int key = kt * 64 + t2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        st[t2][r] = key > vis ? -INFINITY : st[t2][r];
-                    }
-                    mx = fmaxf(mx, st[t2][r]);
-                }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;
             // The running max only moves when some query's max grew by more than 2^RESCALE_LOG2: below
             // that, p <= 2^RESCALE_LOG2 is still exact enough in bf16/fp32 and the O rescale is skipped.
@@ -148,6 +217,7 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 ? 2 : 1)) void attn_varle
                 const float m_new = fmaxf(m_run, mx);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+                asm volatile("" : "+v"(alpha));                 // opaque: keeps the 64 multiplies inside this rare branch
                 m_run = m_new;
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
@@ -155,39 +225,96 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 ? 2 : 1)) void attn_varle
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
             const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
-            float psum = 0.f;
+            const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {neg_m, neg_m};
+            f32x2 psum2 = {0.f, 0.f};
             bf16x8 pb[2][2];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t2][r], scale_log2, neg_m));
-                    psum += p;
-                    pb[t2][r >> 3][r & 7] = f2bf(p);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 s2 = {st[t2][r], st[t2][r + 1]};
+                    const f32x2 e2 = __builtin_elementwise_fma(s2, sc2, nm2);
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                    psum2 += p2;
+                    pb[t2][r >> 3][r & 7] = f2bf(p2[0]);
+                    pb[t2][r >> 3][(r & 7) + 1] = f2bf(p2[1]);
                 }
-            l_run = l_run * alpha + psum;
-            // ---- O^T += V^T . P^T
-            const int gi = lane >> 4, li = lane & 15;
-            const int tr_q = li >> 2, tr_p = li & 3;
+            l_run = l_run * alpha + (psum2[0] + psum2[1]);
+            // ---- O^T += V^T . P^T.  The transposing LDS reads are issued from inline asm: as compiler-visible loads
+            // they would each be preceded by a vmcnt(0) (LDS reads are ordered after every LDS-DMA in flight), which
+            // drains the prefetched tiles.  One group = the 4 reads that feed two MFMAs (the SIMD's other wave covers their
+            // latency).  lgkmcnt(0) is the only wait (LDS returns in order; over-waiting is safe).
+            bf16x4 vl[2], vh[2];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int ch = 4 * dt + 2 * (gi & 1) + (tr_p >> 1);   // 16-B chunk of columns 32dt+16(gi&1)+4p
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2)
+                for (int t2 = 0; t2 < 2; ++t2) {                  // rows 32*t2 + 16*sft (+8 for the high half)
+                    if (t2 == 0)
+                        asm volatile(
+                            "ds_read_b64_tr_b16 %0, %4 offset:16384\n\t"
+                            "ds_read_b64_tr_b16 %1, %5 offset:18432\n\t"
+                            "ds_read_b64_tr_b16 %2, %4 offset:20480\n\t"
+                            "ds_read_b64_tr_b16 %3, %5 offset:22528\n\t"
+                            "s_waitcnt lgkmcnt(0)"
+                            : "=&v"(vl[0]), "=&v"(vh[0]), "=&v"(vl[1]), "=&v"(vh[1])
+                            : "v"(vb[dt][0]), "v"(vb[dt][1])
+                            : "memory");
+                    else
+                        asm volatile(
+                            "ds_read_b64_tr_b16 %0, %4 offset:24576\n\t"
+                            "ds_read_b64_tr_b16 %1, %5 offset:26624\n\t"
+                            "ds_read_b64_tr_b16 %2, %4 offset:28672\n\t"
+                            "ds_read_b64_tr_b16 %3, %5 offset:30720\n\t"
+                            "s_waitcnt lgkmcnt(0)"
+                            : "=&v"(vl[0]), "=&v"(vh[0]), "=&v"(vl[1]), "=&v"(vh[1])
+                            : "v"(vb[dt][0]), "v"(vb[dt][1])
+                            : "memory");
 #pragma unroll
                     for (int sft = 0; sft < 2; ++sft) {
-                        const int r0 = 32 * t2 + 16 * sft + 4 * (gi >> 1) + tr_q;
-                        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (LDS_AS bf16x4*)(sm_v + v_off(r0, ch) + 8 * (tr_p & 1)));
-                        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                            (LDS_AS bf16x4*)(sm_v + v_off(r0 + 8, ch) + 8 * (tr_p & 1)));
-                        const bf16x8 vfrag = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        const bf16x8 vfrag = __builtin_shufflevector(vl[sft], vh[sft], 0, 1, 2, 3, 4, 5, 6, 7);
                         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb[t2][sft], o[dt], 0, 0, 0);
                     }
+                }
+        };
+
+        constexpr int AHEAD = STAGES - 1;                       // tiles kept in flight
+        fetch_page(kt_beg);
+        for (int t = 0; t < AHEAD && kt_beg + t < kt_end; ++t) stage(kt_beg + t);
+        // Q^T fragments: lane (q = ql, half hh) holds Q[q][16ks + 8hh .. +7].  Loaded AFTER the first DMAs were
+        // issued (the latencies overlap) and pinned by an empty asm: from here on the compiler sees registers, not a
+        // pending global load, so it does not drain the DMA queue (vmcnt(0)) at their first use in every tile.
+        {
+            const bf16* qp = q + (int64_t)(q_beg + qrow) * q_stride + (int64_t)h * 128 + 8 * hh;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+        }
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            // this wave's pieces of tile kt have landed (later tiles may still be in flight) ...
+            PROF_T(p0);
+            attn_wait_tiles<PW, AHEAD - 1>(min(AHEAD - 1, kt_end - 1 - kt));
+            asm volatile("" ::: "memory");
+            PROF_T(p1);
+            __builtin_amdgcn_s_barrier();                       // ... everyone's have, and tile kt-1 is consumed
+            asm volatile("" ::: "memory");
+            PROF_T(p2);
+            if (kt + AHEAD < kt_end) stage(kt + AHEAD);         // into the slot of tile kt-1
+            PROF_T(p3);
+            PROF_ADD(0, p0, p1);
+            PROF_ADD(1, p1, p2);
+            PROF_ADD(2, p2, p3);
+            if (kt * 64 <= wave_last_key) {                     // else: tile entirely above this wave's diagonal
+                if (kt * 64 + 63 > wave_first_row + shift) tile(kt, std::true_type{});
+                else tile(kt, std::false_type{});
             }
+            PROF_T(p4);
+            PROF_ADD(3, p3, p4);
+            PROF_ADD(4, p0, p0 + 1);
         }
     }
 
+    PROF_FLUSH;
     // ---- lane (q, hh) holds O[q][32dt + 8(r>>2) + 4hh + (r&3)]
     l_run += __shfl_xor(l_run, 32, 64);
     if (qrow_raw >= lq) return;
@@ -238,23 +365,24 @@ struct VarlenArgs {
     float *ws_acc, *ws_ml;
 };
 
-template <int G, int RB>
+template <int G, int RB, int STAGES>
 void launch_varlen(bool paged, dim3 grid, hipStream_t st, const VarlenArgs& a) {
-    constexpr int smem = 2 * 2 * 64 * 256;
+    constexpr int smem = STAGES * 2 * 64 * 256;
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, STAGES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, STAGES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
     }
     if (paged)
-        attn_varlen_kernel<G, RB, true><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts, a.hkv,
-                                                                        a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
+        attn_varlen_kernel<G, RB, STAGES, true><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
+                                                                                a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
     else
-        attn_varlen_kernel<G, RB, false><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts, a.hkv,
-                                                                         a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
+        attn_varlen_kernel<G, RB, STAGES, false><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
+                                                                                 a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
 }
 
+// Query rows per workgroup: 4-5 waves (8 for G = 8), each 32 rows of one query head.
 int rows_per_block(int g) { return g == 1 ? 128 : g == 2 ? 64 : 32; }
 }  // namespace
 
@@ -303,7 +431,7 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
 #define LAUNCH_VL(GG, RBB)                                                                                                  \
     do {                                                                                                                    \
         dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));      \
-        launch_varlen<GG, RBB>(paged, grid, st, a);                                                                         \
+        launch_varlen<GG, RBB, 2>(paged, grid, st, a);                                                                      \
     } while (0)
     switch (g) {
         case 1: LAUNCH_VL(1, 4); break;

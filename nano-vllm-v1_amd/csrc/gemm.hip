@@ -289,7 +289,14 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
 }
 
 static int32_t dispatch_gemm(const GemmArgs& a) {
-    switch (pick_tile(a.M, a.N, a.split_k)) {
+    static const int s128 = getenv("NVH_GEMM_S128") ? atoi(getenv("NVH_GEMM_S128")) : 0;   // tuning switches
+    static const int s64 = getenv("NVH_GEMM_S64") ? atoi(getenv("NVH_GEMM_S64")) : 0;
+    const Tile tile = pick_tile(a.M, a.N, a.split_k);
+    if (tile == T128x128 && s128 == 3) { launch_gemm<128, 128, 2, 2, 3>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    if (tile == T128x128 && s128 == 4) { launch_gemm<128, 128, 2, 2, 4>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    if (tile == T64x64 && s64 == 6) { launch_gemm<64, 64, 2, 2, 6>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    if (tile == T64x64 && s64 == 8) { launch_gemm<64, 64, 2, 2, 8>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    switch (tile) {
         case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;
         case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;

@@ -293,6 +293,7 @@ class ModelRunner:
                 module.k_cache = self.kv_cache[0, layer_id]
                 module.v_cache = self.kv_cache[1, layer_id]
                 module.max_context = cfg.max_model_len
+                module.split_fn = self.decode_splits
                 layer_id += 1
 
     # -------------------------------------------------------------- per-step input
@@ -325,13 +326,25 @@ class ModelRunner:
             mode, splits = MODE_PACKED, 1
         elif fb["max_seqlen_q"] == 1:
             mode = MODE_DECODE
-            splits = ops.suggest_decode_splits(bs, self.model.model.layers[0].self_attn.num_kv_heads, fb["max_seqlen_k"])
+            splits = self.decode_splits(bs)
         else:
             mode, splits = MODE_PAGED, 1
         return self.native.forward(input_ids, positions, mode=mode, batch=bs, cu_seqlens_q=ctx.cu_seqlens_q,
                                    cu_seqlens_k=ctx.cu_seqlens_k, max_seqlen_q=fb["max_seqlen_q"],
                                    max_seqlen_k=fb["max_seqlen_k"], slot_mapping=ctx.slot_mapping,
                                    context_lens=ctx.context_lens, block_tables=ctx.block_tables, decode_splits=splits)
+
+    def decode_buckets(self) -> list[int]:
+        max_bs = min(self.config.max_num_seqs, 512)
+        return [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+
+    def decode_splits(self, bs: int) -> int:
+        """Key-range count of the decode attention for a batch of `bs`: chosen per graph bucket and for the longest
+        context a sequence may reach, so a captured graph and an eager step of the same batch sum in the same
+        order (enforce_eager does not change a single bit of the output)."""
+        bucket = next((b for b in self.decode_buckets() if b >= bs), bs)
+        hkv = self.model.model.layers[0].self_attn.num_kv_heads
+        return ops.suggest_decode_splits(bucket, hkv, self.config.max_model_len)
 
     def _graph_for(self, fb):
         """The captured graph that fits this step, or None (eager)."""
@@ -382,9 +395,8 @@ class ModelRunner:
     @torch.inference_mode()
     def capture_graphs(self):
         cfg = self.config
-        max_bs = min(cfg.max_num_seqs, 512)
         width = self.graph_width = (cfg.max_model_len + self.block_size - 1) // self.block_size
-        self.graph_bs = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+        self.graph_bs = self.decode_buckets()
         pool = None
         for bs in reversed(self.graph_bs):
             g = _DecodeGraph(self, bs, width, pool)
@@ -417,8 +429,7 @@ class _DecodeGraph:
         self.dev.copy_(self.host)
         set_context(slot_mapping=dv["slot_mapping"], context_lens=dv["context_lens"], block_tables=dv["block_tables"])
         if runner.native is not None:
-            hkv = runner.model.model.layers[0].self_attn.num_kv_heads
-            splits = ops.suggest_decode_splits(bs, hkv, runner.config.max_model_len)
+            splits = runner.decode_splits(bs)
 
             def fwd():
                 return runner.native.forward(dv["input_ids"], dv["positions"], mode=MODE_DECODE, batch=bs,

@@ -54,6 +54,20 @@ def gemm(shapes):
                 break
 
 
+def gemm_vs_library(shapes):
+    """Calibration only: the same shapes through torch's library GEMM (hipBLASLt/rocBLAS), to see what the
+    hardware allows at these sizes.  Not used by the product."""
+    print(f"{'M':>6} {'N':>7} {'K':>6} {'ours us':>9} {'TF':>7} {'lib us':>9} {'TF':>7}")
+    for m, n, k in shapes:
+        copies = max(2, min(128, (600 << 20) // (n * k * 2) + 1))
+        xs = [torch.randn(m, k, device="cuda").to(BF) for _ in range(min(copies, 8))]
+        ws = [(torch.randn(n, k, device="cuda") * 0.05).to(BF) for _ in range(copies)]
+        ours = timeit(lambda i: ops.linear(xs[i % len(xs)], ws[i % copies]), iters=max(50, copies))
+        lib = timeit(lambda i: torch.nn.functional.linear(xs[i % len(xs)], ws[i % copies]), iters=max(50, copies))
+        f = 2 * m * n * k / 1e6
+        print(f"{m:6d} {n:7d} {k:6d} {ours:9.2f} {f / ours:7.1f} {lib:9.2f} {f / lib:7.1f}")
+
+
 def attn_prefill(cases, hq=16, hkv=8):
     print(f"{'Lq':>6} {'Lk':>6} {'us':>9} {'TFLOP/s':>9}")
     d = 128
@@ -95,6 +109,10 @@ if __name__ == "__main__":
               (256, 4096, 1024), (256, 6144, 1024), (256, 1024, 2048), (256, 1024, 3072), (256, 151936, 1024),
               (1, 4096, 1024), (1, 6144, 1024), (1, 1024, 2048), (1, 1024, 3072), (1, 151936, 1024),
               (16, 4096, 1024), (16, 1024, 3072), (64, 6144, 1024), (4096, 4096, 4096)])
+    if "gemmlib" in a.what:
+        gemm_vs_library([(1024, 4096, 1024), (1024, 6144, 1024), (1024, 1024, 2048), (1024, 1024, 3072),
+                         (256, 4096, 1024), (256, 6144, 1024), (256, 1024, 2048), (256, 1024, 3072),
+                         (4096, 4096, 4096), (8192, 8192, 8192)])
     if "prefill" in a.what:
         attn_prefill([(1024, 1024), (1024, 2048), (1024, 4096), (1024, 8192), (128, 128)])
     if "decode" in a.what:
