@@ -16,3 +16,7 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$out/libnanovllm_hip.so" "$here"/.obj/*.o
 echo "built $out/libnanovllm_hip.so"
+# host-path helpers (CPython extension; optional at run time: the Python implementation is used without it)
+PYINC="$(python3 -c 'import sysconfig, numpy; print("-I" + sysconfig.get_paths()["include"], "-I" + numpy.get_include())')"
+gcc -O2 -shared -fPIC -Wall $PYINC "$here/host/hostpath.c" -o "$here/../nanovllm/_hostpath.so"
+echo "built $here/../nanovllm/_hostpath.so"

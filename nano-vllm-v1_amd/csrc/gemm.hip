@@ -233,17 +233,21 @@ void launch_gemm(const GemmArgs& a) {
 }
 
 // Tile choice: the largest tile whose grid (x split_k) still gives every CU a workgroup.
-enum Tile { T16x128, T32x128, T64x128, T64x64, T128x64, T128x128 };
+enum Tile { T16x128, T32x128, T64x128, T64x64, T128x64, T128x128, T256x128 };
 Tile pick_tile(int64_t M, int64_t N, int split_k) {
     if (M <= 16) return T16x128;
     if (M <= 32) return T32x128;
     auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
     if (M <= 64) return T64x128;
+    // very wide outputs with few rows (LM head at decode batch 256): all rows in one tile, so every weight row is
+    // fetched once; three stages, one workgroup per CU
+    static const bool no256 = getenv("NVH_GEMM_NO_256") != nullptr;
+    if (!no256 && M >= 256 && M <= 512 && wgs(256, 128) >= 768) return T256x128;
     if (wgs(128, 128) >= 200) return T128x128;
     if (wgs(128, 64) >= 200) return T128x64;
     return T64x64;
 }
-int tile_bm(Tile t) { return t == T16x128 ? 16 : t == T32x128 ? 32 : (t == T64x128 || t == T64x64) ? 64 : 128; }
+int tile_bm(Tile t) { return t == T16x128 ? 16 : t == T32x128 ? 32 : (t == T64x128 || t == T64x64) ? 64 : t == T256x128 ? 256 : 128; }
 int tile_bn(Tile t) { return (t == T64x64 || t == T128x64) ? 64 : 128; }
 }  // namespace
 static int32_t dispatch_gemm(const GemmArgs& a);
@@ -303,6 +307,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;
         case T128x64: launch_gemm<128, 64, 2, 2, 4>(a); break;
         case T128x128: launch_gemm<128, 128, 2, 2, 2>(a); break;
+        case T256x128: launch_gemm<256, 128, 2, 2, 3>(a); break;
     }
     NVH_CHECK_LAUNCH("gemm_bf16_nt");
     return NVH_OK;

@@ -105,9 +105,15 @@ __global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restric
     const int64_t lo = (int64_t)blockIdx.x * slice_len;
     const int64_t hi = min(vocab, lo + slice_len);
     const void* rp = F32 ? (const void*)((const float*)logits + row * row_stride) : (const void*)((const bf16*)logits + row * row_stride);
-    float t = 1.f;
-    if constexpr (MODE != 0) t = temps[row];
-    ValIdx best{-INFINITY, (int64_t)0x7fffffffffffffffLL};
+    float t = 1.f, inv_t = 1.f;
+    if constexpr (MODE != 0) {
+        t = temps[row];
+        inv_t = 1.0f / t;
+    }
+    // The lane scans increasing indices, so "strictly greater" keeps the lowest index among equals; the index stays
+    // 32-bit (relative to the slice start) until the cross-lane reduction.
+    float best_v = -INFINITY;
+    int best_i = 0x7fffffff;
     // two independent 4-element groups per trip keep two loads in flight per lane
     for (int64_t i0 = lo + (int64_t)threadIdx.x * 4; i0 < hi; i0 += 2048) {
         float v[2][4];
@@ -118,25 +124,40 @@ __global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restric
         for (int u = 0; u < 2; ++u) {
             const int64_t i = u ? i1 : i0;
             if (i >= hi) continue;
-            float e4[4] = {1.f, 1.f, 1.f, 1.f};
-            if constexpr (MODE == 1) {
+            float sc[4];
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc[e] = v[u][e];
+            } else if constexpr (MODE == 1) {
+                // score = z - ln(E), E = -ln(u), u uniform in (0,1): hardware log2 (1 ulp) is ample for noise
                 uint32_t c[4] = {(uint32_t)(i >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)};
                 philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+                constexpr float LN2 = 0.6931471805599453f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) e4[e] = -logf(((float)(c[e] >> 8) + 0.5f) * (1.0f / 16777216.0f));
-            } else if constexpr (MODE == 2) {
+                for (int e = 0; e < 4; ++e) {
+                    const float un = ((float)(c[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+                    const float ex = -LN2 * __builtin_amdgcn_logf(un);                      // Exp(1) sample, > 0
+                    sc[e] = __builtin_fmaf(v[u][e], inv_t, -LN2 * __builtin_amdgcn_logf(ex));
+                }
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) e4[e] = (i + e < hi) ? noise[row * vocab + i + e] : 1.f;
+                for (int e = 0; e < 4; ++e) {
+                    const float ex = (i + e < hi) ? noise[row * vocab + i + e] : 1.f;
+                    sc[e] = v[u][e] / t - logf(fmaxf(ex, 1e-10f));
+                }
             }
+            const int rel = (int)(i - lo);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (i + e < hi) {
-                    float sc = v[u][e];
-                    if constexpr (MODE != 0) sc = v[u][e] / t - logf(fmaxf(e4[e], 1e-10f));
-                    best = better(best, ValIdx{sc, i + e});
+                if (i + e < hi && sc[e] > best_v) {
+                    best_v = sc[e];
+                    best_i = rel + e;
                 }
         }
     }
+    // a lane whose elements are all -inf still offers its first index (rows of -inf resolve to index 0, as a scan would)
+    const int64_t first = lo + (int64_t)threadIdx.x * 4;
+    ValIdx best{best_v, best_i != 0x7fffffff ? lo + best_i : (first < hi ? first : (int64_t)0x7fffffffffffffffLL)};
     best = block_argmax(best, sm_vi);
     if (threadIdx.x == 0) {
         if (gridDim.x == 1) out[row] = best.i;

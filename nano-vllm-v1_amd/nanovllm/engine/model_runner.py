@@ -35,6 +35,11 @@ from ..utils.context import get_context, reset_context, set_context
 from ..utils.loader import has_checkpoint, load_model, load_tensors, synthetic_tensors
 from .sequence import Sequence
 
+try:
+    from .. import _hostpath
+except ImportError:                       # not built: same results from the numpy implementation
+    _hostpath = None
+
 SHM_NAME = "nanovllm"
 SHM_BYTES = 2 ** 20
 
@@ -43,6 +48,14 @@ SHM_BYTES = 2 ** 20
 # host-side batch flattening (device independent; unit-tested on CPU)
 # ------------------------------------------------------------------------------------------
 def flatten_batch(seqs, block_size: int = 256) -> dict:
+    """Per-step tensors of reference model_runner.py:438-495 as numpy arrays: the C helper
+    (csrc/host/hostpath.c) when it is built, else the numpy implementation below (same results)."""
+    if _hostpath is not None:
+        return _hostpath.flatten_batch(seqs, block_size)
+    return _flatten_batch_py(seqs, block_size)
+
+
+def _flatten_batch_py(seqs, block_size: int = 256) -> dict:
     """Per-step tensors of reference model_runner.py:438-495 as numpy arrays.
 
     input_ids / positions int64 [T]; cu_seqlens_q / cu_seqlens_k int32 [B+1]; slot_mapping int32

@@ -295,3 +295,40 @@ def test_shm_control_plane_roundtrip():
     finally:
         shm.close()
         shm.unlink()
+
+
+# ------------------------------------------------------------------ C host path == numpy host path
+def _same_fb(a, b):
+    assert a.keys() == b.keys()
+    for k in a:
+        if isinstance(a[k], np.ndarray) or isinstance(b[k], np.ndarray):
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+def test_c_flatten_batch_equals_numpy_version():
+    from nanovllm.engine import model_runner as MR
+    from nanovllm.engine.sequence import Sequence
+    if MR._hostpath is None:
+        pytest.skip("csrc/host/hostpath.c not built")
+    rng = np.random.default_rng(0)
+    cases = []
+    # decode batch, mixed prefill/decode with page crossings, no block tables (warm-up), zero-token sequences
+    def mk(n_tok, cached, new, table):
+        s = Sequence(rng.integers(0, 10000, n_tok).tolist())
+        s.num_cached_tokens, s.num_new_tokens, s.block_table = cached, new, list(table)
+        return s
+    cases.append([mk(700, 699, 1, [3, 9, 4]), mk(257, 256, 1, [0, 1]), mk(5, 4, 1, [7])])
+    cases.append([mk(700, 300, 250, [3, 9, 4]), mk(1000, 0, 512, [5, 6]), mk(30, 29, 1, [2]), mk(600, 512, 88, [10, 11, 12])])
+    cases.append([mk(64, 0, 64, []), mk(64, 0, 64, [])])
+    cases.append([mk(300, 0, 300, [1, 2]), mk(10, 10, 0, [8])])
+    cases.append([])
+    for seqs in cases:
+        _same_fb(MR._hostpath.flatten_batch(seqs, 256), MR._flatten_batch_py(seqs, 256))
+    # the pickled (windowed) form that tensor-parallel workers receive
+    import pickle
+    seqs = pickle.loads(pickle.dumps(cases[1]))
+    _same_fb(MR._hostpath.flatten_batch(seqs, 256), MR._flatten_batch_py(seqs, 256))
+    with pytest.raises(IndexError):
+        MR._hostpath.flatten_batch([mk(700, 300, 250, [3])], 256)
