@@ -8,12 +8,12 @@
 // ------------------------------------------------------------------ RMSNorm family
 // LPR lanes cooperate on one row (16 for head_dim-sized rows, 64 for hidden-sized rows);
 // each lane keeps up to MAXC 16-byte chunks of its row in registers.
-template <int LPR, int MAXC, bool ADD, bool PARTIALS>
-__global__ __launch_bounds__(256) void rmsnorm_kernel(
+template <int LPR, int MAXC, bool ADD, bool PARTIALS, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
     const bf16* __restrict__ x, int64_t x_stride, bf16* __restrict__ residual,
     const bf16* __restrict__ w, bf16* __restrict__ y, int64_t y_stride,
     int64_t rows, int dim, float eps, const float* __restrict__ partials, int num_partials) {
-    constexpr int RPB = 256 / LPR;                       // rows per block
+    constexpr int RPB = THREADS / LPR;                   // rows per block
     const int lane_in_row = threadIdx.x % LPR;
     const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
     const bool active = row < rows;
@@ -97,7 +97,11 @@ static int32_t launch_rmsnorm(const bf16* x, int64_t xs, bf16* res, const bf16* 
     if (dim <= 128) {
         rmsnorm_kernel<16, 1, ADD, PARTIALS><<<nvh_cdiv(rows, 16), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 1024) {
-        rmsnorm_kernel<64, 2, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        // decode-sized batches: one wave per workgroup, so a few hundred rows still reach every CU
+        if (rows <= 1024)
+            rmsnorm_kernel<64, 2, ADD, PARTIALS, 64><<<(unsigned)rows, 64, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        else
+            rmsnorm_kernel<64, 2, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 4096) {
         rmsnorm_kernel<64, 8, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else {

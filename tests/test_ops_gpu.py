@@ -209,7 +209,8 @@ def test_embedding_vocab_parallel(ops):
 
 
 GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024), (33, 1024, 3072), (64, 1024, 256),
-               (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256)]
+               (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256),
+               (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128)]   # 64x96 tile; 256x128 LM-head tile (one / two row tiles)
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
