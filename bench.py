@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--context", type=int, default=1024)
     ap.add_argument("--no-extras", action="store_true", help="skip sweeps, long prefill and the CPU baseline")
+    ap.add_argument("--model", default="qwen3-0.6b", help="directory name under nano-vllm-v1_amd/model_configs (default: the headline model)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,7 +266,9 @@ def main():
     max_len = 8192 + 64
     pages_decode = b * ((ctx0 + total_steps + 64 + PAGE) // PAGE + 1)
     pages = max(pages_decode, 8 * (max_len // PAGE + 1)) + 16
-    cfg = Config(str(MODEL_DIR), max_num_batched_tokens=1024, max_num_seqs=max(b, 8), max_model_len=max_len,
+    model_dir = MODEL_DIR.parent / args.model
+    model_name = args.model.replace("qwen3", "Qwen3").replace("b", "B")
+    cfg = Config(str(model_dir), max_num_batched_tokens=1024, max_num_seqs=max(b, 8), max_model_len=max_len,
                  tensor_parallel_size=world, enforce_eager=False, chunked_prefill=True, num_kvcache_blocks=pages)
     hf = cfg.hf_config
     t_init = time.perf_counter()
@@ -296,11 +299,11 @@ def main():
     contexts = [s.num_cached_tokens - args.steps / 2 for s in seqs]          # mean context over the timed steps
     step_bytes, w_bytes, kv_tok = algorithmic_bytes_per_decode_step(hf, contexts, world)
     step_gbs = step_bytes / (dt / args.steps) / 1e9
-    out = dict(metric="decode tok/s (Qwen3-0.6B, bf16; prefill tok/s and roofline fractions in `prefill`/`roofline`)",
+    out = dict(metric=f"decode tok/s ({model_name}, bf16; prefill tok/s and roofline fractions in `prefill`/`roofline`)",
                value=round(value, 1), unit="tok/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling="strong", vs_baseline=None,
-               dtype="bf16", data="synthetic token ids, random-init weights (Qwen3-0.6B architecture)",
-               config=dict(workload=f"Qwen3-0.6B TP={world} bf16 decode, B={b} sequences x ~{ctx0} context tokens, "
+               dtype="bf16", data=f"synthetic token ids, random-init weights ({model_name} architecture)",
+               config=dict(workload=f"{model_name} TP={world} bf16 decode, B={b} sequences x ~{ctx0} context tokens, "
                                     "chunked_prefill on, max_num_batched_tokens=1024, hipGraph decode",
                            batch=b, context=ctx0, parallelism=f"tp{world}", kv_page=PAGE),
                step_roofline=dict(bound="hbm", achieved=round(step_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",

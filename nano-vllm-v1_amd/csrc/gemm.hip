@@ -44,10 +44,11 @@ __device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
 }
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
+__global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split) {
-    static_assert(WAVES_N * WAVES_M == 4, "4 waves");
+    constexpr int NW = WAVES_N * WAVES_M;                 // waves per workgroup (4; 2 for the skinny decode tiles)
+    static_assert(NW == 4 || NW == 2, "2 or 4 waves");
     constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
     constexpr int TN = WN / 16, TM = WM / 16;             // 16x16 MFMA tiles per wave
     static_assert(TN >= 1 && TM >= 1, "wave tile");
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int A_GROUPS = BN / 8, B_GROUPS = BM / 8;   // 8-row x 128-B pieces = one DMA each
     constexpr int PIECES = A_GROUPS + B_GROUPS;
-    constexpr int PW = (PIECES + 3) / 4;                  // DMA instructions per wave per tile (uniform)
+    constexpr int PW = (PIECES + NW - 1) / NW;            // DMA instructions per wave per tile (uniform)
     constexpr int AHEAD = STAGES - 1;                     // tiles kept in flight
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
     bool piece_is_w[PW];
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-        int p = wave + i * 4;
+        int p = wave + i * NW;
         if (p >= PIECES) p -= PIECES;                     // duplicate piece keeps the per-wave count uniform
         const bool is_b = p >= A_GROUPS;
         const int grp = is_b ? p - A_GROUPS : p;
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(
         // W rows are interleaved in blocks of 16: [gate 16b..16b+15 | up 16b..16b+15], so tile i (even) holds
         // gate and tile i+1 the matching up columns in the same lanes.  y[m][16b + ..] = silu(gate) * up with the
         // rounding points of the separate kernels: GEMM output -> bf16, silu -> bf16, product -> bf16.
-        static_assert(TN % 2 == 0, "SwiGLU epilogue pairs 16-row tiles");
+        // pairs of 16-row tiles: configurations with an odd TN are never launched with SWIGLU (dispatch_gemm)
 #pragma unroll
-        for (int i = 0; i < TN; i += 2) {
+        for (int i = 0; i + 1 < TN; i += 2) {
             const int n = n0 + wn * WN + i * 16;                 // first interleaved row of the gate block
             if (n >= N) continue;
             const int col = (n >> 5) * 16 + fq * 4;              // output column
@@ -216,7 +217,7 @@ void launch_gemm_nt(const GemmArgs& a) {
     const int ktiles = a.K / BK;
     const int k_per_split = (int)nvh_cdiv(ktiles, a.split_k) * BK;
     dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
-    kern<<<grid, 256, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split);
+    kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split);
 }
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
@@ -233,10 +234,14 @@ void launch_gemm(const GemmArgs& a) {
 }
 
 // Tile choice: the largest tile whose grid (x split_k) still gives every CU a workgroup.
-enum Tile { T16x128, T32x128, T64x128, T64x64, T128x64, T128x128, T256x128 };
+enum Tile { T16x32, T32x32, T16x128, T32x128, T64x128, T64x64, T128x64, T128x128, T256x128 };
 Tile pick_tile(int64_t M, int64_t N, int split_k) {
-    if (M <= 16) return T16x128;
-    if (M <= 32) return T32x128;
+    // decode batches: 128-row weight tiles leave most CUs idle unless the output is very wide; 32-row tiles in
+    // two-wave workgroups (three fit a CU) keep the weight stream spread over the chip
+    static const bool no_skinny = getenv("NVH_GEMM_NO_SKINNY") != nullptr;
+    const bool narrow = nvh_cdiv(N, 128) * split_k < 384 && !no_skinny;
+    if (M <= 16) return narrow ? T16x32 : T16x128;
+    if (M <= 32) return (narrow && split_k == 1) ? T32x32 : T32x128;      // with split-K the 128-row tile measured faster
     auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
     if (M <= 64) return T64x128;
     // very wide outputs with few rows (LM head at decode batch 256): all rows in one tile, so every weight row is
@@ -247,8 +252,8 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     if (wgs(128, 64) >= 200) return T128x64;
     return T64x64;
 }
-int tile_bm(Tile t) { return t == T16x128 ? 16 : t == T32x128 ? 32 : (t == T64x128 || t == T64x64) ? 64 : t == T256x128 ? 256 : 128; }
-int tile_bn(Tile t) { return (t == T64x64 || t == T128x64) ? 64 : 128; }
+int tile_bm(Tile t) { return (t == T16x128 || t == T16x32) ? 16 : (t == T32x128 || t == T32x32) ? 32 : (t == T64x128 || t == T64x64) ? 64 : t == T256x128 ? 256 : 128; }
+int tile_bn(Tile t) { return (t == T16x32 || t == T32x32) ? 32 : (t == T64x64 || t == T128x64) ? 64 : 128; }
 }  // namespace
 static int32_t dispatch_gemm(const GemmArgs& a);
 
@@ -257,12 +262,15 @@ extern "C" int64_t nvh_gemm_workspace_bytes(int64_t M, int64_t N, int32_t split_
 }
 
 extern "C" int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K) {
-    // Split only when even the smallest tile leaves most CUs idle: enough workgroups for 256 CUs,
-    // at least 4 k-tiles (256 k) per split, at most 16 slabs.
-    const Tile t = pick_tile(M, N, 1);
+    // Split only when even the smallest tile leaves most CUs idle: enough workgroups for 256 CUs (three rounds of
+    // the two-wave decode tiles, of which three fit a CU), at least 4 k-tiles (256 k) per split, at most 16 slabs.
+    Tile t = pick_tile(M, N, 1);
+    if (t == T32x32) t = T32x128;                              // 17..32 rows: split on the 128-row tile's terms
+    const bool skinny = t == T16x32;
     const int64_t tiles = nvh_cdiv(N, tile_bn(t)) * nvh_cdiv(M, tile_bm(t));
-    if (tiles >= 160) return 1;
-    int64_t s = nvh_cdiv(256, tiles);
+    const int64_t want = skinny ? 768 : 256;
+    if (tiles >= (skinny ? 512 : 160)) return 1;
+    int64_t s = nvh_cdiv(want, tiles);
     const int64_t kmax = K / 256 > 1 ? K / 256 : 1;
     if (s > kmax) s = kmax;
     if (s > 16) s = 16;
@@ -301,6 +309,14 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
     if (tile == T64x64 && s64 == 6) { launch_gemm<64, 64, 2, 2, 6>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
     if (tile == T64x64 && s64 == 8) { launch_gemm<64, 64, 2, 2, 8>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
     switch (tile) {
+        case T16x32:
+            if (a.swiglu) launch_gemm<32, 32, 1, 2, 8>(a);      // gate and up tile of a pair in the same wave
+            else launch_gemm<16, 32, 2, 1, 8>(a);
+            break;
+        case T32x32:
+            if (a.swiglu) launch_gemm<32, 32, 1, 2, 8>(a);
+            else launch_gemm<32, 32, 2, 1, 8>(a);
+            break;
         case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;
         case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
