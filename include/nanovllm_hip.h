@@ -211,6 +211,12 @@ int32_t nvh_comm_open_peers(nvh_comm* comm, const void* handles);
 void* nvh_comm_buffer(nvh_comm* comm);
 int64_t nvh_comm_max_bytes(nvh_comm* comm);
 int32_t nvh_allreduce_bf16(nvh_comm* comm, const void* in, void* out, int64_t count, nvh_stream_t stream);
+/* All-reduce fused with its consumer, the residual add + RMSNorm after a row-parallel projection
+ * (layers/linear.py:407-409 followed by layers/layernorm.py:95-141): residual += sum over ranks of in[rows, dim]
+ * (each rounded to bf16 as the separate calls do), y = RMSNorm(residual) * weight.  One kernel per rank, one-shot
+ * exchange (meant for decode-sized messages); same bits as nvh_allreduce_bf16 + nvh_add_rmsnorm. */
+int32_t nvh_allreduce_add_rmsnorm_bf16(nvh_comm* comm, const void* in, void* residual, const void* weight, void* y,
+                                       int64_t rows, int64_t dim, float eps, nvh_stream_t stream);
 /* C3: logits gather of ParallelLMHead.forward (layers/embed_head.py:205-209): on `root`,
  * out[rows, world*cols] = column-wise concatenation in rank order of every rank's in[rows, cols]
  * (cols % 8 == 0, rows*cols*2 <= max_bytes); `out` is ignored on the other ranks. */

@@ -148,6 +148,62 @@ __global__ __launch_bounds__(kThreads) void gather_cols_kernel(CommDev c, const 
     if (threadIdx.x == 0) c.epoch[blockIdx.x] = e0 + 2;
 }
 
+// One-shot all-reduce fused with the residual add + RMSNorm that consumes it (the pattern after every row-parallel
+// projection): block b owns rows [b*rpb, (b+1)*rpb) on every rank, one wave per row.  Per row: sum of the ranks'
+// staged rows in rank order (fp32, rounded to bf16 exactly like the stand-alone all-reduce), + residual -> new
+// residual, RMSNorm -> y.  Same bits as nvh_allreduce_bf16 followed by nvh_add_rmsnorm.
+template <int MAXC>
+__global__ __launch_bounds__(kThreads) void allreduce_add_rmsnorm_kernel(CommDev c, const bf16* __restrict__ in, bf16* __restrict__ residual,
+                                                                         const bf16* __restrict__ w, bf16* __restrict__ y, int64_t rows,
+                                                                         int dim, float eps, int64_t rpb, int staged) {
+    const uint32_t e0 = c.epoch[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r_lo = blockIdx.x * rpb, r_hi = min(r_lo + rpb, rows);
+    const int nchunk = dim >> 3;
+    if (staged) {
+        const int64_t p_lo = r_lo * nchunk, p_hi = r_hi * nchunk;
+        for (int64_t p = p_lo + threadIdx.x; p < p_hi; p += kThreads)
+            reinterpret_cast<bf16x8*>(c.stage[c.rank])[p] = reinterpret_cast<const bf16x8*>(in)[p];
+    }
+    comm_barrier(c, e0 + 1, staged);
+    for (int64_t r = r_lo + wave; r < r_hi; r += kThreads / 64) {
+        float v[MAXC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                const bf16x8 s8 = sum_ranks(c, r * nchunk + ch);
+                const bf16x8 res = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + ch * 8);
+                bf16x8 nr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = bf2f(s8[j]) + bf2f(res[j]);
+                    nr[j] = f2bf(x);
+                    v[i][j] = x;
+                    ss += x * x;
+                }
+                *reinterpret_cast<bf16x8*>(residual + r * (int64_t)dim + ch * 8) = nr;
+            }
+        }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / sqrtf(ss / (float)dim + eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int ch = lane + i * 64;
+            if (ch < nchunk) {
+                const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + ch * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(v[i][j] * inv)) * bf2f(wv[j]));
+                *reinterpret_cast<bf16x8*>(y + r * (int64_t)dim + ch * 8) = o;
+            }
+        }
+    }
+    comm_barrier(c, e0 + 2, false);
+    if (threadIdx.x == 0) c.epoch[blockIdx.x] = e0 + 2;
+}
+
 }  // namespace
 
 extern "C" int32_t nvh_comm_handle_bytes(void) { return (int32_t)sizeof(hipIpcMemHandle_t); }
@@ -238,6 +294,34 @@ extern "C" int32_t nvh_allreduce_bf16(nvh_comm* c, const void* in, void* out, in
         allreduce_twoshot_kernel<<<nb, kThreads, 0, st>>>(c->dev, (const bf16*)in, (bf16*)out, packs, slice, per, in_place ? 0 : 1);
     }
     NVH_CHECK_LAUNCH("nvh_allreduce_bf16");
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_allreduce_add_rmsnorm_bf16(nvh_comm* c, const void* in, void* residual, const void* weight, void* y,
+                                                  int64_t rows, int64_t dim, float eps, nvh_stream_t stream) {
+    NVH_REQUIRE(c && in && residual && weight && y, NVH_EINVAL, "nvh_allreduce_add_rmsnorm_bf16: null pointer");
+    NVH_REQUIRE(c->opened, NVH_EINVAL, "nvh_allreduce_add_rmsnorm_bf16: peers not mapped (nvh_comm_open_peers)");
+    NVH_REQUIRE(rows >= 0 && dim > 0 && dim % 8 == 0 && dim <= 8192 && rows * dim * 2 <= c->max_bytes, NVH_EINVAL,
+                "nvh_allreduce_add_rmsnorm_bf16: [%ld, %ld] needs dim %% 8 == 0, dim <= 8192 and must fit %ld staging bytes", (long)rows,
+                (long)dim, (long)c->max_bytes);
+    NVH_REQUIRE(nvh_aligned16(in) && nvh_aligned16(residual) && nvh_aligned16(weight) && nvh_aligned16(y), NVH_EINVAL,
+                "nvh_allreduce_add_rmsnorm_bf16: 16-byte alignment required");
+    const char* own = (const char*)c->dev.stage[c->dev.rank];
+    const bool in_place = (const char*)in == own;
+    NVH_REQUIRE(in_place || (const char*)in + rows * dim * 2 <= own || (const char*)in >= own + c->max_bytes, NVH_EINVAL,
+                "nvh_allreduce_add_rmsnorm_bf16: input overlaps the staging area without starting at it");
+    if (rows == 0) return NVH_OK;
+    const int nb = (int)std::min<int64_t>(kMaxBlocks, nvh_cdiv(rows, kThreads / 64));
+    const int64_t rpb = nvh_cdiv(rows, nb);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_ARN(MAXC)                                                                                                   \
+    allreduce_add_rmsnorm_kernel<MAXC><<<nb, kThreads, 0, st>>>(c->dev, (const bf16*)in, (bf16*)residual, (const bf16*)weight, \
+                                                                (bf16*)y, rows, (int)dim, eps, rpb, in_place ? 0 : 1)
+    if (dim <= 1024) LAUNCH_ARN(2);
+    else if (dim <= 4096) LAUNCH_ARN(8);
+    else LAUNCH_ARN(16);
+#undef LAUNCH_ARN
+    NVH_CHECK_LAUNCH("nvh_allreduce_add_rmsnorm_bf16");
     return NVH_OK;
 }
 

@@ -87,6 +87,10 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
         NVH_REQUIRE(t * h * 2 <= nvh_comm_max_bytes(comm), NVH_EINVAL, "nvh_qwen3_forward: %ld tokens exceed the exchange staging area", (long)t);
         proj_out = (bf16*)nvh_comm_buffer(comm);   // partial sums are produced straight into the exported area
     }
+    // decode-sized messages: the sum, the residual add and the norm are one kernel; larger ones keep the two-shot
+    // all-reduce (less xGMI traffic) followed by the norm
+    static const bool no_fused = getenv("NVH_NO_FUSED_EXCHANGE") != nullptr;
+    const bool fused_exchange = comm && !no_fused && t * h * 2 <= (int64_t)(1 << 20);
     FWD(nvh_embedding(st->input_ids, md->embed, w.residual, t, h, md->vocab_start, md->vocab_rows, stream));
     if (comm) FWD(nvh_allreduce_bf16(comm, w.residual, w.residual, t * h, stream));
     bool pending_slabs = false;         // the previous projection left split-K slabs in w.slabs
@@ -96,6 +100,8 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
         // ---- input norm: layer 0 normalises the embedding; later layers add the MLP output first
         if (l == 0) {
             FWD(nvh_rmsnorm(w.residual, h, md->input_norm[l], w.x, h, t, h, md->eps, stream));
+        } else if (comm && fused_exchange) {
+            FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->input_norm[l], w.x, t, h, md->eps, stream));
         } else {
             FWD(nvh_add_rmsnorm(pending_y, w.residual, md->input_norm[l], w.x, t, h, md->eps,
                                 pending_slabs ? w.slabs : nullptr, pending_count, stream));
@@ -132,8 +138,12 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
             FWD(nvh_add_rmsnorm(nullptr, w.residual, md->post_norm[l], w.x, t, h, md->eps, w.slabs, so, stream));
         } else {
             FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, proj_out, h, t, h, qsz, 1, nullptr, stream));
-            if (comm) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
-            FWD(nvh_add_rmsnorm(w.y, w.residual, md->post_norm[l], w.x, t, h, md->eps, nullptr, 0, stream));
+            if (comm && fused_exchange) {
+                FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->post_norm[l], w.x, t, h, md->eps, stream));
+            } else {
+                if (comm) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
+                FWD(nvh_add_rmsnorm(w.y, w.residual, md->post_norm[l], w.x, t, h, md->eps, nullptr, 0, stream));
+            }
         }
         // ---- MLP
         if (md->gate_up_inter && md->gate_up_inter[l]) {
@@ -149,14 +159,18 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
             pending_y = nullptr;
         } else {
             FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, proj_out, h, t, h, md->inter, 1, nullptr, stream));
-            if (comm) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
+            if (comm && !fused_exchange) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
             pending_slabs = false;
             pending_count = 0;
-            pending_y = w.y;
+            pending_y = w.y;                 // (with the fused exchange the partial sums stay in proj_out)
         }
     }
-    FWD(nvh_add_rmsnorm(pending_y, w.residual, md->final_norm, hidden_out, t, h, md->eps,
-                        pending_slabs ? w.slabs : nullptr, pending_count, stream));
+    if (comm && fused_exchange) {
+        FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->final_norm, hidden_out, t, h, md->eps, stream));
+    } else {
+        FWD(nvh_add_rmsnorm(pending_y, w.residual, md->final_norm, hidden_out, t, h, md->eps,
+                            pending_slabs ? w.slabs : nullptr, pending_count, stream));
+    }
     return NVH_OK;
 }
 

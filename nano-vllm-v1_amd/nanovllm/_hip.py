@@ -44,6 +44,7 @@ SIGNATURES = {
     "nvh_comm_buffer": (vp, [vp]),
     "nvh_comm_max_bytes": (i64, [vp]),
     "nvh_allreduce_bf16": (i32, [vp, vp, vp, i64, vp]),
+    "nvh_allreduce_add_rmsnorm_bf16": (i32, [vp, vp, vp, vp, vp, i64, i64, f32, vp]),
     "nvh_gather_cols_bf16": (i32, [vp, vp, vp, i64, i64, i32, vp]),
     "nvh_comm_error": (i32, [vp]),
     "nvh_comm_destroy": (i32, [vp]),

@@ -60,6 +60,15 @@ class XgmiComm:
                   torch.cuda.current_stream().cuda_stream)
         return out
 
+    def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+        """residual += sum over ranks of x (in place); returns RMSNorm(residual) * weight.  x, residual: [rows, dim] bf16."""
+        assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
+        rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+        y = torch.empty_like(residual)
+        _hip.call("nvh_allreduce_add_rmsnorm_bf16", self._h, x.data_ptr(), residual.data_ptr(), weight.data_ptr(), y.data_ptr(),
+                  rows, dim, float(eps), torch.cuda.current_stream().cuda_stream)
+        return y
+
     def gather_cols(self, x: torch.Tensor, root: int = 0) -> torch.Tensor | None:
         """x [rows, cols] per rank -> [rows, world*cols] on `root` (rank order along the columns), None elsewhere."""
         assert x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 2

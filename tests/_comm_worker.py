@@ -57,6 +57,25 @@ def main():
         static.copy_(x2)
         g.replay()
         assert torch.equal(res.cpu(), ref2), f"graph replay {k}"
+    # all-reduce fused with residual add + RMSNorm == the two separate calls, bit for bit
+    from nanovllm import ops
+    for rows, dim in ((1, 1024), (37, 1024), (256, 1024), (5, 5120), (3, 8192)):
+        x, _ = expect(rows * dim, 300 + rows)
+        x = x.view(rows, dim)
+        g = torch.Generator().manual_seed(7)
+        res = torch.randn(rows, dim, generator=g).to(torch.bfloat16).cuda()
+        w = (torch.randn(dim, generator=g) * 0.1 + 1).to(torch.bfloat16).cuda()
+        summed = c.all_reduce(x.clone())
+        res_a = res.clone()
+        y_a, _ = ops.add_rmsnorm(summed, res_a, w, 1e-6)
+        res_b = res.clone()
+        y_b = c.all_reduce_add_rmsnorm(x.clone(), res_b, w, 1e-6)
+        assert torch.equal(y_a, y_b) and torch.equal(res_a, res_b), f"fused exchange {rows}x{dim}"
+        buf = c.buffer(rows * dim).view(rows, dim)          # producer wrote into the staging area
+        buf.copy_(x)
+        res_c = res.clone()
+        y_c = c.all_reduce_add_rmsnorm(buf, res_c, w, 1e-6)
+        assert torch.equal(y_a, y_c) and torch.equal(res_a, res_c), f"fused exchange in place {rows}x{dim}"
     # logits gather: column-wise concatenation on rank 0
     for rows, cols in ((1, 8), (3, 18992), (64, 1000 * 8)):
         g = torch.Generator().manual_seed(900 + rows)
