@@ -124,20 +124,28 @@ class Driver:
             s.append_token(int(t))
 
 
-def sync_all(distributed):
+def note(msg):
+    """Progress marker on stderr (NANOVLLM_BENCH_VERBOSE=1): tells where a multi-rank run stopped."""
+    if os.environ.get("NANOVLLM_BENCH_VERBOSE") == "1":
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def sync_all(distributed, runner=None):
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    if runner is not None and getattr(runner, "comm", None) is not None:
+        runner.comm.check()                     # raises if an exchange timed out instead of reporting a bogus time
 
 
 def time_decode(driver, seqs, steps, warmup, distributed):
     for _ in range(warmup):
         driver.decode_step(seqs)
-    sync_all(distributed)
+    sync_all(distributed, driver.runner)
     t0 = time.perf_counter()
     for _ in range(steps):
         driver.decode_step(seqs)
-    sync_all(distributed)
+    sync_all(distributed, driver.runner)
     dt = time.perf_counter() - t0
     if distributed:
         t = torch.tensor([dt], device="cuda")
@@ -272,8 +280,10 @@ def main():
                  tensor_parallel_size=world, enforce_eager=False, chunked_prefill=True, num_kvcache_blocks=pages)
     hf = cfg.hf_config
     t_init = time.perf_counter()
+    note("building the runner")
     runner = ModelRunner(cfg, rank, [])
     init_s = time.perf_counter() - t_init
+    note("runner ready")
     driver = Driver(runner)
     g = torch.Generator().manual_seed(0)
 
@@ -283,6 +293,7 @@ def main():
     # ---- prefill of the decode batch: B prompts x context tokens, one 1024-token chunk per step
     seqs = [driver.new_seq(p) for p in prompts(b, ctx0)]
     ptimes = driver.prefill(seqs, 1024)
+    note("prefill done")
     steady = [x for x in ptimes[len(ptimes) // 4:]] or ptimes
     chunk_s = sum(x[0] for x in steady) / len(steady)
     chunk_tokens = sum(x[1] for x in steady) / len(steady)
@@ -295,6 +306,7 @@ def main():
 
     # ---- the timed region: K decode steps of B sequences
     dt = time_decode(driver, seqs, args.steps, args.warmup, distributed)
+    note("decode timed")
     value = b * args.steps / dt
     contexts = [s.num_cached_tokens - args.steps / 2 for s in seqs]          # mean context over the timed steps
     step_bytes, w_bytes, kv_tok = algorithmic_bytes_per_decode_step(hf, contexts, world)
@@ -327,6 +339,7 @@ def main():
             k = 32
             d2 = time_decode(driver, sub, k, 4, distributed)
             sb, _, _ = algorithmic_bytes_per_decode_step(hf, [s.num_cached_tokens - k / 2 for s in sub], world)
+            note(f"sweep B={bb} done")
             sweep[f"B{bb}"] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
                                    hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
         out["decode_sweep"] = sweep

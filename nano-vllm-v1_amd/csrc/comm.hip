@@ -14,6 +14,7 @@
 // Replaces the NCCL all-reduce of RowParallelLinear.forward (reference layers/linear.py:407-409) and of
 // VocabParallelEmbedding.forward (layers/embed_head.py:128-129).
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -29,7 +30,9 @@ struct CommDev {                    // passed to kernels by value
     uint32_t* flags[kMaxWorld];     // flags[r]: rank r's flag block (own or IPC-mapped)
     bf16* stage[kMaxWorld];         // stage[r]: rank r's staging area
     uint32_t* epoch;                // [kMaxBlocks] own device memory: barriers passed so far per block
-    uint32_t* fault;                // own device memory: nonzero once a spin timed out
+    uint32_t* fault;                // own device memory: [0] nonzero once a spin timed out (1 + silent rank),
+                                    // [1..3] block, expected epoch, epoch seen of the first timeout
+    uint64_t spin_limit;            // wall-clock ticks (100 MHz) a flag may stay behind
     int rank, world;
 };
 
@@ -56,10 +59,17 @@ __device__ __forceinline__ void comm_barrier(const CommDev& c, uint32_t e, bool 
         __hip_atomic_store(c.flags[t] + blockIdx.x * kMaxWorld + c.rank, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const uint32_t* mine = c.flags[c.rank] + blockIdx.x * kMaxWorld + t;
         const uint64_t t0 = wall_clock64();
-        while ((int32_t)(__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - e) < 0) {
+        uint32_t seen;
+        while ((int32_t)((seen = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) - e) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > kSpinLimitTicks) {
-                __hip_atomic_store(c.fault, 1u + (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // after the first timeout nothing waits any more: the step finishes (with garbage) and the host,
+            // which checks the fault word, raises instead of sitting through one timeout per exchange
+            if (wall_clock64() - t0 > c.spin_limit || __hip_atomic_load(c.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                if (atomicCAS(c.fault, 0u, 1u + (uint32_t)t) == 0u) {
+                    c.fault[1] = blockIdx.x;
+                    c.fault[2] = e;
+                    c.fault[3] = seen;
+                }
                 break;
             }
         }
@@ -220,8 +230,8 @@ extern "C" int32_t nvh_comm_create(int32_t rank, int32_t world, int64_t max_byte
     c->dev.world = world;
     hipError_t e = hipExtMallocWithFlags(&c->region, kFlagBytes + max_bytes, hipDeviceMallocUncached);
     if (e == hipSuccess) e = hipMemset(c->region, 0, kFlagBytes);
-    if (e == hipSuccess) e = hipMalloc(&c->local, (kMaxBlocks + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->local, 0, (kMaxBlocks + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->local, (kMaxBlocks + 4) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->local, 0, (kMaxBlocks + 4) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         nvh_set_error("nvh_comm_create: %s", hipGetErrorString(e));
@@ -232,6 +242,8 @@ extern "C" int32_t nvh_comm_create(int32_t rank, int32_t world, int64_t max_byte
     }
     c->dev.epoch = (uint32_t*)c->local;
     c->dev.fault = c->dev.epoch + kMaxBlocks;
+    const char* ms = getenv("NVH_COMM_TIMEOUT_MS");            // default 20 s; tests and debugging shorten it
+    c->dev.spin_limit = ms && atoll(ms) > 0 ? (uint64_t)atoll(ms) * 100000ull : kSpinLimitTicks;
     c->dev.flags[rank] = (uint32_t*)c->region;
     c->dev.stage[rank] = (bf16*)((char*)c->region + kFlagBytes);
     *out = c;
@@ -349,14 +361,16 @@ extern "C" int32_t nvh_gather_cols_bf16(nvh_comm* c, const void* in, void* out, 
 // Synchronises the device; returns 0 when no exchange has timed out, else 1 + the first silent rank seen.
 extern "C" int32_t nvh_comm_error(nvh_comm* c) {
     if (!c) return 0;
-    uint32_t f = 0;
-    hipError_t e = hipMemcpy(&f, c->dev.fault, sizeof(f), hipMemcpyDeviceToHost);
+    uint32_t f[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpy(f, c->dev.fault, sizeof(f), hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
         nvh_set_error("nvh_comm_error: %s", hipGetErrorString(e));
         return NVH_ELAUNCH;
     }
-    if (f) nvh_set_error("tensor-parallel exchange timed out: rank %d waited 20 s for rank %u", c->dev.rank, f - 1);
-    return (int32_t)f;
+    if (f[0])
+        nvh_set_error("tensor-parallel exchange timed out: rank %d, block %u waited for rank %u to reach epoch %u (saw %u)",
+                      c->dev.rank, f[1], f[0] - 1, f[2], f[3]);
+    return (int32_t)f[0];
 }
 
 extern "C" int32_t nvh_comm_destroy(nvh_comm* c) {

@@ -87,24 +87,41 @@ class XgmiComm:
         if rc:
             raise _hip.HipError(_hip.lib().nvh_last_error().decode())
 
-    def self_test(self, sizes=(8, 1 << 12, 1 << 18, 3 << 18)) -> bool:
-        """Compare against torch.distributed on a few message sizes (one- and two-shot); identical on every rank."""
+    def self_test(self, sizes=(8, 1 << 12, 1 << 18, 3 << 18), soak: int = 64) -> bool:
+        """Start-up verification against torch.distributed: a few message sizes (one- and two-shot), then a soak of
+        back-to-back fused exchanges and gathers shaped like decode steps.  The verdict is agreed between the ranks."""
         ok = True
-        for i, n in enumerate(sizes):
-            if n * 2 > self.max_bytes:
-                continue
-            g = torch.Generator(device="cpu").manual_seed(1234 + 17 * i + self.rank)
-            x = torch.randn(n, generator=g, dtype=torch.float32).to(torch.bfloat16).cuda()
-            ref = x.float()
-            dist.all_reduce(ref, group=self.group)
-            try:
+        try:
+            for i, n in enumerate(sizes):
+                if n * 2 > self.max_bytes:
+                    continue
+                g = torch.Generator(device="cpu").manual_seed(1234 + 17 * i + self.rank)
+                x = torch.randn(n, generator=g, dtype=torch.float32).to(torch.bfloat16).cuda()
+                ref = x.float()
+                dist.all_reduce(ref, group=self.group)
                 got = self.all_reduce(x.clone())
                 self.check()
-            except _hip.HipError as e:               # a peer never answered: report, let every rank agree below
-                print(f"[nanovllm] rank {self.rank}: {e}", file=sys.stderr)
-                ok = False
-                break
-            ok = ok and bool(torch.allclose(got.float(), ref, atol=0.0, rtol=2.0 ** -7))
+                ok = ok and bool(torch.allclose(got.float(), ref, atol=0.0, rtol=2.0 ** -7))
+            # soak: every call changes the data, the results of all calls are folded into one checksum row
+            rows, dim = 8, 1024
+            if ok and rows * dim * 2 <= self.max_bytes:
+                g = torch.Generator(device="cpu").manual_seed(99 + self.rank)
+                xs = torch.randn(soak, rows, dim, generator=g).to(torch.bfloat16).cuda()
+                w = torch.ones(dim, dtype=torch.bfloat16, device="cuda")
+                res = torch.zeros(rows, dim, dtype=torch.bfloat16, device="cuda")
+                res_ref = torch.zeros(rows, dim, dtype=torch.float32, device="cuda")
+                for k in range(soak):
+                    self.all_reduce_add_rmsnorm(xs[k], res, w, 1e-6)
+                    if k % 8 == 7 and rows * 8 * 2 <= self.max_bytes:
+                        self.gather_cols(xs[k, :, :8].contiguous(), 0)
+                total = xs.float().sum(0)
+                dist.all_reduce(total, group=self.group)
+                self.check()
+                # res accumulated bf16-rounded sums; compare loosely (rounding per step), exact agreement is tested elsewhere
+                ok = ok and bool((res.float() - total).abs().max() <= 0.05 * total.abs().max() + 0.5)
+        except _hip.HipError as e:                       # a peer never answered: report, let every rank agree below
+            print(f"[nanovllm] rank {self.rank}: {e}", file=sys.stderr)
+            ok = False
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return bool(flag.item())

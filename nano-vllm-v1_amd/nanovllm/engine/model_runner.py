@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import os
 import pickle
+import time
 from multiprocessing.shared_memory import SharedMemory
 
 import numpy as np
@@ -398,10 +399,13 @@ class ModelRunner:
 
     @torch.inference_mode()
     def run(self, seqs):
+        t0 = time.perf_counter()
         logits, temps, need_host = self.forward_logits(seqs)
         token_ids = None
         if self.rank == 0:
             token_ids = [] if logits is None else self.sampler(logits, temps).tolist()
+        if self.comm is not None and time.perf_counter() - t0 > 2.0:
+            self.comm.check()                   # a step this slow may have sat through an exchange timeout: raise, do not go on
         return token_ids, need_host
 
     # -------------------------------------------------------------- hipGraph decode
