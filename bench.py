@@ -107,7 +107,7 @@ class Driver:
         """Only rank 0 samples; every rank must feed the same ids to the next step (the engine's control
         plane does this with the scheduler's sequences; here one small broadcast stands in for it)."""
         if n and dist.is_initialized() and dist.get_world_size() > 1:
-            t = torch.tensor(toks if toks is not None else [0] * n, dtype=torch.int64, device="cuda")
+            t = torch.tensor(toks if toks is not None else [0] * n, dtype=torch.int64, device=collective_device())
             dist.broadcast(t, 0)
             toks = t.tolist()
         return toks
@@ -122,6 +122,11 @@ class Driver:
             s.num_cached_tokens += 1
             s.num_new_tokens = 0
             s.append_token(int(t))
+
+
+def collective_device():
+    """RCCL moves device tensors; the gloo rehearsal (ranks sharing one GPU) gets host tensors."""
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
 
 
 def note(msg):
@@ -148,7 +153,7 @@ def time_decode(driver, seqs, steps, warmup, distributed):
     sync_all(distributed, driver.runner)
     dt = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device=collective_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt

@@ -21,21 +21,57 @@ from . import _hip
 _ACTIVE: "XgmiComm | None" = None
 
 
+def _on_host(group=None) -> bool:
+    """True when the torch.distributed backend works on host memory (gloo: CPU rehearsals, several ranks sharing
+    one test GPU).  Device tensors are then staged through the host explicitly; gloo's own device-tensor path was
+    seen to hang with two processes on one GPU."""
+    return dist.get_backend(group) != "nccl"
+
+
+def _dist_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over the ranks through torch.distributed (RCCL in deployment)."""
+    if t.is_cuda and _on_host(group):
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 class XgmiComm:
     def __init__(self, rank: int, world: int, max_bytes: int, group=None):
+        """Collective: every rank of `group` must call it.  Raises HipError on EVERY rank if any rank could not
+        allocate, export or map the exchange regions (the ranks agree on the outcome before anything is used)."""
         lib = _hip.lib()
         self.rank, self.world, self.group = rank, world, group
         self.max_bytes = (int(max_bytes) + 15) // 16 * 16
-        handle = ctypes.c_void_p()
-        _hip.check(lib.nvh_comm_create(rank, world, self.max_bytes, ctypes.byref(handle)), "nvh_comm_create")
-        self._h = handle
-        n = lib.nvh_comm_handle_bytes()
-        mine = ctypes.create_string_buffer(n)
-        _hip.check(lib.nvh_comm_get_handle(self._h, mine), "nvh_comm_get_handle")
+        self._h = None
+        problem, blob = None, None
+        try:
+            handle = ctypes.c_void_p()
+            _hip.check(lib.nvh_comm_create(rank, world, self.max_bytes, ctypes.byref(handle)), "nvh_comm_create")
+            self._h = handle
+            mine = ctypes.create_string_buffer(lib.nvh_comm_handle_bytes())
+            _hip.check(lib.nvh_comm_get_handle(self._h, mine), "nvh_comm_get_handle")
+            blob = mine.raw
+        except _hip.HipError as e:
+            problem = str(e)
         gathered: list = [None] * world
-        dist.all_gather_object(gathered, mine.raw, group=group)
-        _hip.check(lib.nvh_comm_open_peers(self._h, b"".join(gathered)), "nvh_comm_open_peers")
-        dist.barrier(group=group)
+        dist.all_gather_object(gathered, blob, group=group)
+        if problem is None and all(b is not None for b in gathered):
+            try:
+                _hip.check(lib.nvh_comm_open_peers(self._h, b"".join(gathered)), "nvh_comm_open_peers")
+            except _hip.HipError as e:
+                problem = str(e)
+        elif problem is None:
+            problem = "a peer could not create its exchange region"
+        verdicts: list = [None] * world
+        dist.all_gather_object(verdicts, problem, group=group)      # doubles as the barrier before first use
+        bad = [f"rank {r}: {p}" for r, p in enumerate(verdicts) if p is not None]
+        if bad:
+            self.close()
+            raise _hip.HipError("xGMI exchange unavailable (" + "; ".join(bad) + ")")
         self.buffer_ptr = int(lib.nvh_comm_buffer(self._h))
 
     def buffer(self, numel: int) -> torch.Tensor:
@@ -90,7 +126,7 @@ class XgmiComm:
     def self_test(self, sizes=(8, 1 << 12, 1 << 18, 3 << 18), soak: int = 64) -> bool:
         """Start-up verification against torch.distributed: a few message sizes (one- and two-shot), then a soak of
         back-to-back fused exchanges and gathers shaped like decode steps.  The verdict is agreed between the ranks."""
-        ok = True
+        ok, timed_out = True, False
         try:
             for i, n in enumerate(sizes):
                 if n * 2 > self.max_bytes:
@@ -98,7 +134,7 @@ class XgmiComm:
                 g = torch.Generator(device="cpu").manual_seed(1234 + 17 * i + self.rank)
                 x = torch.randn(n, generator=g, dtype=torch.float32).to(torch.bfloat16).cuda()
                 ref = x.float()
-                dist.all_reduce(ref, group=self.group)
+                _dist_sum(ref, self.group)
                 got = self.all_reduce(x.clone())
                 self.check()
                 ok = ok and bool(torch.allclose(got.float(), ref, atol=0.0, rtol=2.0 ** -7))
@@ -115,16 +151,18 @@ class XgmiComm:
                     if k % 8 == 7 and rows * 8 * 2 <= self.max_bytes:
                         self.gather_cols(xs[k, :, :8].contiguous(), 0)
                 total = xs.float().sum(0)
-                dist.all_reduce(total, group=self.group)
+                _dist_sum(total, self.group)
                 self.check()
                 # res accumulated bf16-rounded sums; compare loosely (rounding per step), exact agreement is tested elsewhere
                 ok = ok and bool((res.float() - total).abs().max() <= 0.05 * total.abs().max() + 0.5)
         except _hip.HipError as e:                       # a peer never answered: report, let every rank agree below
             print(f"[nanovllm] rank {self.rank}: {e}", file=sys.stderr)
-            ok = False
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+            ok, timed_out = False, True
+        flag = torch.tensor([1 if ok else 0, 0 if timed_out else 1], dtype=torch.int32,
+                            device="cpu" if _on_host(self.group) else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        return bool(flag.item())
+        self.self_test_timed_out = flag[1].item() == 0     # some rank waited in vain for a peer (as opposed to wrong sums)
+        return bool(flag[0].item())
 
     def close(self) -> None:
         if self._h is not None:
@@ -132,15 +170,26 @@ class XgmiComm:
             self._h = None
 
 
+fallback_reason: "str | None" = None      # why the last install() returned None: disabled | setup | timeout | mismatch
+
+
 def install(rank: int, world: int, max_bytes: int, group=None) -> "XgmiComm | None":
     """Create the peer path for this process, verify it, make it the one `all_reduce` uses.  Returns None
     (and says so on stderr) when NANOVLLM_XGMI_AR=0 or the verification fails; callers then run on RCCL."""
-    global _ACTIVE
+    global _ACTIVE, fallback_reason
+    fallback_reason = None
     if os.environ.get("NANOVLLM_XGMI_AR", "1") == "0":
+        fallback_reason = "disabled"
         return None
-    comm = XgmiComm(rank, world, max_bytes, group)
+    try:
+        comm = XgmiComm(rank, world, max_bytes, group)
+    except _hip.HipError as e:
+        print(f"[nanovllm] rank {rank}: {e}; using torch.distributed", file=sys.stderr)
+        fallback_reason = "setup"
+        return None
     if not comm.self_test():
-        print(f"[nanovllm] rank {rank}: xGMI all-reduce self-test FAILED; using torch.distributed", file=sys.stderr)
+        fallback_reason = "timeout" if comm.self_test_timed_out else "mismatch"
+        print(f"[nanovllm] rank {rank}: xGMI all-reduce self-test FAILED ({fallback_reason}); using torch.distributed", file=sys.stderr)
         comm.close()
         return None
     _ACTIVE = comm
@@ -163,14 +212,14 @@ def gather_cols(x: torch.Tensor, root: int = 0) -> torch.Tensor | None:
     if _ACTIVE is not None and _ACTIVE.fits(x) and x.shape[-1] % 8 == 0:
         return _ACTIVE.gather_cols(x, root)
     world, rank = dist.get_world_size(), dist.get_rank()
-    parts = [torch.empty_like(x) for _ in range(world)] if rank == root else None
-    dist.gather(x, parts, root)
-    return torch.cat(parts, -1) if rank == root else None
+    src = x.cpu() if (x.is_cuda and _on_host()) else x
+    parts = [torch.empty_like(src) for _ in range(world)] if rank == root else None
+    dist.gather(src, parts, root)
+    return torch.cat(parts, -1).to(x.device) if rank == root else None
 
 
 def all_reduce(y: torch.Tensor) -> torch.Tensor:
     """In-place sum over the tensor-parallel ranks."""
     if _ACTIVE is not None and _ACTIVE.fits(y):
         return _ACTIVE.all_reduce(y)
-    dist.all_reduce(y)
-    return y
+    return _dist_sum(y)

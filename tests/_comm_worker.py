@@ -17,7 +17,8 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
     c = comm.XgmiComm(rank, world, 8 << 20)
-    assert c.self_test(), "self-test against gloo failed"
+    if not c.self_test():
+        raise RuntimeError("self-test: exchange timed out" if c.self_test_timed_out else "self-test against gloo: wrong sums")
 
     def expect(n, seed):
         parts = [torch.randn(n, generator=torch.Generator().manual_seed(seed * 100 + r)).to(torch.bfloat16) for r in range(world)]
@@ -113,4 +114,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import faulthandler
+    faulthandler.dump_traceback_later(75, exit=False)      # a hung rank shows where before the test's deadline kills it
+    try:
+        main()
+    except Exception as e:  # noqa: BLE001
+        if "exchange timed out" in str(e):       # a peer was not scheduled on the shared device: see run_ranks()
+            print(f"rank not co-scheduled: {e}", flush=True)
+            os._exit(77)
+        raise

@@ -18,6 +18,8 @@ def main():
     rank, world, port, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     os.environ["LOCAL_RANK"] = "0"
     os.environ["NANOVLLM_NATIVE"] = "0" if mode == "modules" else "1"
+    if mode == "fallback":                       # no peer exchange: operator modules + torch.distributed collectives
+        os.environ["NANOVLLM_XGMI_AR"] = "0"
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
     from conftest import TINY
     from test_model_gpu import TINY_DIR, hf_named, seq
@@ -29,8 +31,10 @@ def main():
     cfg = Config(TINY_DIR, max_num_batched_tokens=1024, max_num_seqs=8, max_model_len=2048, tensor_parallel_size=world,
                  enforce_eager=(mode != "graph"), num_kvcache_blocks=12, chunked_prefill=True)
     runner = ModelRunner(cfg, rank, [])
-    assert comm.active() is not None, "xGMI exchange not installed"
-    assert (runner.native is not None) == (mode != "modules")
+    if mode != "fallback" and comm.active() is None and comm.fallback_reason == "timeout":
+        raise RuntimeError("start-up self-test: exchange timed out")
+    assert (comm.active() is not None) == (mode != "fallback"), "xGMI exchange state"
+    assert (runner.native is not None) == (mode not in ("modules", "fallback"))
     shape = M.ModelShape(**TINY)
     weights = M.random_weights(shape, seed=0, std=0.05)
     runner.load_weights(hf_named(weights, shape))
@@ -67,7 +71,8 @@ def main():
             st.block_table = list(s.block_table)
     if mode == "graph":
         assert runner.graphs
-    runner.comm.check()
+    if runner.comm is not None:
+        runner.comm.check()
     if rank == 0:
         tok, need = runner.run(seqs)                 # sampler on rank 0 only
         assert len(tok) == 3
@@ -81,4 +86,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import faulthandler
+    faulthandler.dump_traceback_later(75, exit=False)      # a hung rank shows where before the test's deadline kills it
+    try:
+        main()
+    except Exception as e:  # noqa: BLE001
+        if "exchange timed out" in str(e):       # a peer was not scheduled on the shared device: see run_ranks()
+            print(f"rank not co-scheduled: {e}", flush=True)
+            os._exit(77)
+        raise
