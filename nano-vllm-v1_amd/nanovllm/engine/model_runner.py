@@ -146,12 +146,15 @@ class ModelRunner:
         self.external_group = dist.is_initialized()
         self.shm = None
 
+        # NANOVLLM_SHARE_DEVICE=1: every rank on device 0 with gloo as the control plane (rehearsal on a one-GPU box)
+        share_device = os.environ.get("NANOVLLM_SHARE_DEVICE", "0") == "1"
         if self.external_group:
             assert dist.get_world_size() == self.world_size and dist.get_rank() == rank
         elif self.world_size > 1:
             port = int(os.environ.get("NANOVLLM_PORT", "2333"))
-            dist.init_process_group("nccl", f"tcp://127.0.0.1:{port}", world_size=self.world_size, rank=rank)
-        device_index = int(os.environ.get("LOCAL_RANK", rank)) if self.external_group else rank
+            dist.init_process_group("gloo" if share_device else "nccl", f"tcp://127.0.0.1:{port}",
+                                    world_size=self.world_size, rank=rank)
+        device_index = int(os.environ.get("LOCAL_RANK", rank)) if self.external_group else (0 if share_device else rank)
         torch.cuda.set_device(device_index)
         self.device = torch.device("cuda", device_index)
         _hip.check(_hip.lib().nvh_device_check(device_index), "nvh_device_check")

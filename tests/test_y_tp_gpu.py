@@ -20,3 +20,39 @@ def test_tp2_logits_match_single_rank_oracle(mode):
     for r, (rc, out) in enumerate(results):
         assert rc == 0 and f"rank {r} OK" in out, f"rank {r} rc={rc}\n{out[-3000:]}"
     print(results[0][1][-300:])
+
+
+@pytest.mark.gpu
+def test_engine_spawned_tp2_generate_from_checkpoint(tmp_path):
+    """`LLM(tensor_parallel_size=2)` end to end: spawned rank 1, shared-memory control channel, safetensors
+    checkpoint through the shard loaders, chunked prefill + decode graphs; every generated id is checked against
+    the single-rank CPU oracle by teacher forcing."""
+    import json
+    import shutil
+    from safetensors.torch import save_file
+    from conftest import TINY
+    from test_model_gpu import TINY_DIR, hf_named
+    from test_engine_gpu import check_teacher_forced
+    from test_y_comm_gpu import NOT_COSCHEDULED, _free_port
+    from oracle import ref_model as M
+
+    shape = M.ModelShape(**TINY)
+    w = M.random_weights(shape, seed=0, std=0.05)
+    model_dir = tmp_path / "tiny"
+    shutil.copytree(TINY_DIR, model_dir)
+    save_file({k: v.clone() for k, v in hf_named(w, shape)}, str(model_dir / "model.safetensors"))
+    out = tmp_path / "out.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NVH_COMM_TIMEOUT_MS="5000")
+    p = subprocess.run([sys.executable, "-u", os.path.join(HERE, "_engine_tp_worker.py"), str(model_dir), str(out), str(_free_port())],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=140)
+    if p.returncode == NOT_COSCHEDULED:
+        pytest.skip("ranks sharing one device were not co-scheduled (exchange timeout)")
+    assert p.returncode == 0 and "engine OK" in p.stdout, p.stdout[-3000:]
+    r = json.loads(out.read_text())
+    assert len(r["completions"]) == 4
+    exact = total = 0
+    for prompt, completion in zip(r["prompts"], r["completions"]):
+        assert len(completion) == 6
+        exact += check_teacher_forced((shape, w), prompt, completion)
+        total += len(completion)
+    assert exact >= total - 2, f"only {exact}/{total} ids equal the oracle's argmax"
