@@ -188,59 +188,135 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
     }
 }
 
-// Merge per-range partials: ONE WAVE per output row (sequence/token x query head), 4 rows per workgroup,
-// no LDS and no barriers.  Lane s fetches the (max, sum) of range s (<= 64 ranges per pass), the wave
-// reduces them with shuffles, then every lane accumulates its 2 output columns over the ranges with
-// independent 8-byte loads; ranges that saw no key (sum 0) are skipped.
+// Merge per-range partials of one output row (sequence/token x query head).  Both kernels below compute the same
+// bits: range s goes to partial accumulator s mod 4 in increasing s, the row is ((p0 + p1) + (p2 + p3)) / L with
+// L summed by the same wave reduction; ranges that saw no key (sum 0) weigh 0.
+//  * wave-per-row (4 rows per workgroup, no LDS): many rows (prefill with key ranges, large decode batches);
+//  * workgroup-per-row (wave w owns accumulator w): few rows, where the chain of dependent loads of one wave
+//    would be the whole cost.  With `ctx_lens` it only visits the ranges the decode kernel gave keys to.
+__device__ __forceinline__ int active_ranges(const int32_t* ctx_lens, int64_t bh, int hq, int num_splits) {
+    if (!ctx_lens) return num_splits;
+    const int ctx = ctx_lens[bh / hq];
+    if (ctx <= 0) return 0;
+    const int chunk = (((ctx + num_splits - 1) / num_splits) + 63) & ~63;     // as attn_decode_kernel
+    return (ctx + chunk - 1) / chunk;
+}
+
 __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
                                                                   const float* __restrict__ ws_ml,
-                                                                  bf16* __restrict__ out, int num_splits, int64_t rows) {
+                                                                  bf16* __restrict__ out, int num_splits, int64_t rows,
+                                                                  const int32_t* __restrict__ ctx_lens, int hq) {
     const int lane = threadIdx.x & 63;
     const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bh >= rows) return;
+    const int active = active_ranges(ctx_lens, bh, hq, num_splits);
     const f32x2* ml = reinterpret_cast<const f32x2*>(ws_ml) + bh * num_splits;
-    // pass 1: row maximum over all ranges
     float m_loc = -INFINITY;
-    for (int s0 = 0; s0 < num_splits; s0 += 64) {
+    for (int s = lane; s < active; s += 64) {
+        const f32x2 v = ml[s];
+        if (v[1] > 0.f) m_loc = fmaxf(m_loc, v[0]);
+    }
+    const float M = wave_max(m_loc);
+    const float mu = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f;
+    f32x2 A[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const f32x2* acc = reinterpret_cast<const f32x2*>(ws_acc + bh * num_splits * 128) + lane;
+    for (int s0 = 0; s0 < active; s0 += 64) {
         const int s = s0 + lane;
-        if (s < num_splits) {
+        float wgt = 0.f, l = 0.f;
+        if (s < active) {
             const f32x2 v = ml[s];
-            if (v[1] > 0.f) m_loc = fmaxf(m_loc, v[0]);
+            l = v[1];
+            wgt = l > 0.f ? __builtin_amdgcn_exp2f(v[0] - mu) : 0.f;
         }
+        L += l * wgt;
+        const int n = min(64, active - s0);
+        for (int j0 = 0; j0 < n; j0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float wj = __shfl(wgt, (j0 + u) & 63, 64);
+                if (j0 + u < n && wj != 0.f) {                     // wave-uniform
+                    const f32x2 v = acc[(int64_t)(s0 + j0 + u) * 64];
+                    A[u][0] += v[0] * wj;
+                    A[u][1] += v[1] * wj;
+                }
+            }
+        }
+    }
+    L = wave_sum(L);
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    const float a0 = (A[0][0] + A[1][0]) + (A[2][0] + A[3][0]), a1 = (A[0][1] + A[1][1]) + (A[2][1] + A[3][1]);
+    bf16x2 o = {f2bf(a0 * inv), f2bf(a1 * inv)};
+    *reinterpret_cast<bf16x2*>(out + bh * 128 + lane * 2) = o;
+}
+
+__global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const float* __restrict__ ws_acc,
+                                                                      const float* __restrict__ ws_ml,
+                                                                      bf16* __restrict__ out, int num_splits,
+                                                                      const int32_t* __restrict__ ctx_lens, int hq) {
+    __shared__ f32x2 part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t bh = blockIdx.x;
+    const int active = active_ranges(ctx_lens, bh, hq, num_splits);
+    const f32x2* ml = reinterpret_cast<const f32x2*>(ws_ml) + bh * num_splits;
+    // every wave derives the row maximum and the weights itself (<= 256 ranges: 4 records per lane)
+    f32x2 rec[4];
+    float m_loc = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = i * 64 + lane;
+        rec[i] = f32x2{-INFINITY, 0.f};
+        if (s < active) rec[i] = ml[s];
+        if (rec[i][1] > 0.f) m_loc = fmaxf(m_loc, rec[i][0]);
     }
     const float M = wave_max(m_loc);
     const float mu = (M == -INFINITY) ? 0.f : M;
     float L = 0.f;
     f32x2 A = {0.f, 0.f};
     const f32x2* acc = reinterpret_cast<const f32x2*>(ws_acc + bh * num_splits * 128) + lane;
-    for (int s0 = 0; s0 < num_splits; s0 += 64) {
-        const int s = s0 + lane;
-        float wgt = 0.f, l = 0.f;
-        if (s < num_splits) {
-            const f32x2 v = ml[s];
-            l = v[1];
-            wgt = l > 0.f ? __builtin_amdgcn_exp2f(v[0] - mu) : 0.f;
-        }
-        L += l * wgt;
-        const int n = min(64, num_splits - s0);
-#pragma unroll 4
-        for (int j = 0; j < n; ++j) {
-            const float wj = __shfl(wgt, j, 64);
-            if (wj != 0.f) {                                   // wave-uniform
-                const f32x2 v = acc[(int64_t)(s0 + j) * 64];
-                A[0] += v[0] * wj;
-                A[1] += v[1] * wj;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i * 64 >= active) break;                               // block-uniform
+        const float wgt = rec[i][1] > 0.f ? __builtin_amdgcn_exp2f(rec[i][0] - mu) : 0.f;
+        L += rec[i][1] * wgt;
+        const int n = min(64, active - i * 64);
+        for (int j0 = w; j0 < n; j0 += 16) {                       // ranges w, w+4, .. of this block of 64
+            f32x2 v[4];
+            float wj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + 4 * u;
+                wj[u] = j < n ? __shfl(wgt, j & 63, 64) : 0.f;
+                v[u] = f32x2{0.f, 0.f};
+                if (wj[u] != 0.f) v[u] = acc[(int64_t)(i * 64 + j) * 64];      // wave-uniform; loads go out together
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (wj[u] != 0.f) {
+                    A[0] += v[u][0] * wj[u];
+                    A[1] += v[u][1] * wj[u];
+                }
             }
         }
     }
-    L = wave_sum(L);
-    const float inv = L > 0.f ? 1.0f / L : 0.f;
-    bf16x2 o = {f2bf(A[0] * inv), f2bf(A[1] * inv)};
-    *reinterpret_cast<bf16x2*>(out + bh * 128 + lane * 2) = o;
+    part[w][lane] = A;
+    __syncthreads();
+    if (w == 0) {
+        L = wave_sum(L);
+        const float inv = L > 0.f ? 1.0f / L : 0.f;
+        const f32x2 p0 = part[0][lane], p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
+        const float a0 = (p0[0] + p1[0]) + (p2[0] + p3[0]), a1 = (p0[1] + p1[1]) + (p2[1] + p3[1]);
+        bf16x2 o = {f2bf(a0 * inv), f2bf(a1 * inv)};
+        *reinterpret_cast<bf16x2*>(out + bh * 128 + lane * 2) = o;
+    }
 }
 
-int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits, hipStream_t st) {
-    attn_decode_combine_kernel<<<(unsigned)nvh_cdiv(rows, 4), 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, rows);
+int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits,
+                                const int32_t* ctx_lens, int hq, hipStream_t st) {
+    if (rows <= 2048 && num_splits <= 256)
+        attn_decode_combine_row_kernel<<<(unsigned)rows, 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, ctx_lens, hq);
+    else
+        attn_decode_combine_kernel<<<(unsigned)nvh_cdiv(rows, 4), 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, rows, ctx_lens, hq);
     NVH_CHECK_LAUNCH("attn_combine");
     return NVH_OK;
 }
@@ -307,7 +383,7 @@ int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz)
 #undef LAUNCH_DEC
     NVH_CHECK_LAUNCH(name);
     if (a.num_splits > 1)
-        return nvh_launch_attn_combine(ws_acc, ws_ml, a.out, a.batch * a.num_q_heads, a.num_splits, a.st);
+        return nvh_launch_attn_combine(ws_acc, ws_ml, a.out, a.batch * a.num_q_heads, a.num_splits, a.context_lens, (int)a.num_q_heads, a.st);
     return NVH_OK;
 }
 }  // namespace

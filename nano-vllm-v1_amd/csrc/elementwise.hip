@@ -8,17 +8,99 @@
 // ------------------------------------------------------------------ RMSNorm family
 // LPR lanes cooperate on one row (16 for head_dim-sized rows, 64 for hidden-sized rows);
 // each lane keeps up to MAXC 16-byte chunks of its row in registers.
-template <int LPR, int MAXC, bool ADD, bool PARTIALS, int THREADS = 256>
+// With PARTIALS the input is the sum of `num_partials` fp32 split-K slabs, rounded once to bf16 as the GEMM
+// would have.  The slabs are always summed the same way whatever the launch shape: slab p goes to partial sum
+// p mod 4 in increasing p, the total is (s0 + s1) + (s2 + s3).  WIDE (a handful of rows, many slabs): four waves
+// per row, wave w gathers partial sum w, the first wave finishes the row.
+template <int LPR, int MAXC, bool ADD, bool PARTIALS, int THREADS = 256, bool WIDE = false>
 __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
     const bf16* __restrict__ x, int64_t x_stride, bf16* __restrict__ residual,
     const bf16* __restrict__ w, bf16* __restrict__ y, int64_t y_stride,
     int64_t rows, int dim, float eps, const float* __restrict__ partials, int num_partials) {
-    constexpr int RPB = THREADS / LPR;                   // rows per block
+    static_assert(!WIDE || (PARTIALS && LPR == 64 && THREADS == 256), "WIDE: four waves on one row of slabs");
+    constexpr int RPB = WIDE ? 1 : THREADS / LPR;        // rows per block
     const int lane_in_row = threadIdx.x % LPR;
-    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+    const int64_t row = (int64_t)blockIdx.x * RPB + (WIDE ? 0 : threadIdx.x / LPR);
     const bool active = row < rows;
     const int nchunk = dim >> 3;
     const int64_t r = active ? row : rows - 1;           // inactive lanes shadow the last row
+
+    __shared__ float wide_part[WIDE ? 3 : 1][WIDE ? MAXC : 1][WIDE ? 64 : 1][8];
+    if constexpr (WIDE) {
+        const int wave = threadIdx.x >> 6;
+        float acc[MAXC][8];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+        }
+        const int64_t slab = rows * (int64_t)dim;
+        for (int p = wave; p < num_partials; p += 4) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = lane_in_row + i * LPR;
+                if (c < nchunk) {
+                    const float* src = partials + p * slab + r * (int64_t)dim + c * 8;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(src), b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { acc[i][j] += a[j]; acc[i][4 + j] += b[j]; }
+                }
+            }
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wide_part[wave - 1][i][lane_in_row][j] = acc[i][j];
+            }
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        // first wave: (s0 + s1) + (s2 + s3), then the row as below
+        float v[MAXC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane_in_row + i * LPR;
+            if (c < nchunk) {
+                float xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = (acc[i][j] + wide_part[0][i][lane_in_row][j]) + (wide_part[1][i][lane_in_row][j] + wide_part[2][i][lane_in_row][j]);
+                    xv[j] = bf2f(f2bf(t));
+                }
+                if constexpr (ADD) {
+                    bf16x8 t = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + c * 8);
+                    bf16x8 nr;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        xv[j] = xv[j] + bf2f(t[j]);
+                        nr[j] = f2bf(xv[j]);
+                    }
+                    *reinterpret_cast<bf16x8*>(residual + r * (int64_t)dim + c * 8) = nr;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[i][j] = xv[j];
+                    ss += xv[j] * xv[j];
+                }
+            }
+        }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / sqrtf(ss / (float)dim + eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = lane_in_row + i * LPR;
+            if (c < nchunk) {
+                bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(v[i][j] * inv)) * bf2f(wv[j]));
+                *reinterpret_cast<bf16x8*>(y + r * y_stride + c * 8) = o;
+            }
+        }
+        return;
+    }
 
     float v[MAXC][8];
     float ss = 0.f;
@@ -28,7 +110,12 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
         if (c < nchunk) {
             float xv[8];
             if constexpr (PARTIALS) {
-                float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                float acc[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
+                }
                 const float* src0 = partials + r * (int64_t)dim + c * 8;
                 const int64_t slab = rows * (int64_t)dim;
                 int p = 0;
@@ -42,16 +129,19 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { acc[j] += a[u][j]; acc[4 + j] += b[u][j]; }
-                }
-                for (; p < num_partials; ++p) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + p * slab);
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + p * slab + 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+                        for (int j = 0; j < 4; ++j) { acc[u][j] += a[u][j]; acc[u][4 + j] += b[u][j]; }
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] = bf2f(f2bf(acc[j]));   // GEMM output rounds to bf16
+                for (int u = 0; u < 3; ++u) {
+                    if (p + u < num_partials) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab);
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { acc[u][j] += a[j]; acc[u][4 + j] += b[j]; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = bf2f(f2bf((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])));   // GEMM output rounds to bf16
             } else {
                 bf16x8 t = *reinterpret_cast<const bf16x8*>(x + r * x_stride + c * 8);
 #pragma unroll
@@ -98,7 +188,9 @@ static int32_t launch_rmsnorm(const bf16* x, int64_t xs, bf16* res, const bf16* 
         rmsnorm_kernel<16, 1, ADD, PARTIALS><<<nvh_cdiv(rows, 16), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 1024) {
         // decode-sized batches: one wave per workgroup, so a few hundred rows still reach every CU
-        if (rows <= 1024)
+        if (PARTIALS && rows <= 64 && np >= 8)
+            rmsnorm_kernel<64, 2, ADD, PARTIALS, 256, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        else if (rows <= 1024)
             rmsnorm_kernel<64, 2, ADD, PARTIALS, 64><<<(unsigned)rows, 64, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
         else
             rmsnorm_kernel<64, 2, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
