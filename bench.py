@@ -282,7 +282,7 @@ def main():
     model_dir = MODEL_DIR.parent / args.model
     model_name = args.model.replace("qwen3", "Qwen3").replace("b", "B")
     cfg = Config(str(model_dir), max_num_batched_tokens=1024, max_num_seqs=max(b, 8), max_model_len=max_len,
-                 tensor_parallel_size=world, enforce_eager=False, chunked_prefill=True, num_kvcache_blocks=pages)
+                 tensor_parallel_size=world, enforce_eager=os.environ.get("NANOVLLM_BENCH_EAGER", "0") == "1", chunked_prefill=True, num_kvcache_blocks=pages)
     hf = cfg.hf_config
     t_init = time.perf_counter()
     note("building the runner")
@@ -357,6 +357,25 @@ def main():
         out["prefill_8k"] = dict(tok_s=round(sum(x[1] for x in lt) / tot_s, 1), tflops=round(tot_f / tot_s / 1e12, 2),
                                  mfma_frac=round(tot_f / tot_s / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                  ms_per_chunk=[round(x[0] * 1e3, 3) for x in lt])
+        # ---- decode at other context lengths.  The sequences are declared cached up to their last token, so the
+        # attention streams pages left behind by the runs above: same bytes and launches as a real batch, no
+        # meaningful ids (timing only).
+        ctx_sweep = {}
+        for bb, cc in ((min(b, 256), 128), (min(b, 32), 8192)):
+            k = 32
+            driver.reset()
+            if bb * ((cc + k + 8) // PAGE + 1) > driver.num_pages:
+                continue
+            fake = [driver.new_seq(p) for p in prompts(bb, cc)]
+            for s in fake:
+                s.num_cached_tokens = cc - 1
+                driver.grow(s, cc)
+            d2 = time_decode(driver, fake, k, 4, distributed)
+            sb, _, _ = algorithmic_bytes_per_decode_step(hf, [s.num_cached_tokens - k / 2 for s in fake], world)
+            note(f"context sweep B={bb} ctx={cc} done")
+            ctx_sweep[f"B{bb}_ctx{cc}"] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
+                                               hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
+        out["decode_context_sweep"] = ctx_sweep
         if rank == 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(hf)
     if rank == 0:

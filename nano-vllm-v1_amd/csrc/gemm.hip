@@ -243,6 +243,8 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     if (M <= 16) return narrow ? T16x32 : T16x128;
     if (M <= 32) return (narrow && split_k == 1) ? T32x32 : T32x128;      // with split-K the 128-row tile measured faster
     auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
+    static const int force = getenv("NVH_GEMM_FORCE_TILE") ? atoi(getenv("NVH_GEMM_FORCE_TILE")) : -1;   // tuning switch
+    if (force >= T16x128 && force <= T256x128) return (Tile)force;
     if (M <= 64) return T64x128;
     // very wide outputs with few rows (LM head at decode batch 256): all rows in one tile, so every weight row is
     // fetched once; three stages, one workgroup per CU

@@ -18,6 +18,7 @@ Same contract as the reference's engine/model_runner.py:49-715 -
 from __future__ import annotations
 
 import os
+import sys
 import pickle
 import time
 from multiprocessing.shared_memory import SharedMemory
@@ -165,6 +166,10 @@ class ModelRunner:
             vocab_shard = hf.vocab_size // self.world_size
             nbytes = 2 * max(config.max_num_batched_tokens * hf.hidden_size, config.max_num_seqs * vocab_shard)
             self.comm = comm.install(rank, self.world_size, nbytes)
+            if self.comm is None and not self.enforce_eager:
+                # operator modules + torch.distributed collectives: keep them out of graph capture
+                print(f"[nanovllm] rank {rank}: no peer exchange, running tensor parallel eagerly", file=sys.stderr)
+                self.enforce_eager = True
 
         dtype = model_dtype(hf)
         if dtype != torch.bfloat16:
