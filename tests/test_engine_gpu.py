@@ -123,3 +123,39 @@ def test_serving_harness_accounts_every_request(weights):
     assert r["input_tokens"] == 24 * 40 and r["output_tokens"] == 24 * 7
     assert r["mean_ttft_ms"] > 0 and r["mean_tpot_ms"] > 0 and r["mean_latency_s"] * 1e3 >= r["mean_ttft_ms"]
     assert abs(r["throughput_tok_s"] - (24 * 47) / r["total_time_s"]) < 1e-6
+
+
+def test_generate_text_prompts_with_a_tokenizer(weights, tmp_path):
+    """Text in, text out (reference llm_engine.py:113-114 tokenizer load, :131-134 encode, :265-267 decode): a model
+    directory with tokenizer files is served through AutoTokenizer; eos comes from the tokenizer and ends a request
+    unless ignore_eos.  The tokenizer is a word-level one built here over the tiny model's 1024 ids."""
+    import json
+    import shutil
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from nanovllm import LLM, SamplingParams
+    shape, w = weights
+    model_dir = tmp_path / "tiny-tok"
+    shutil.copytree(TINY_DIR, model_dir)
+    tok = Tokenizer(models.WordLevel({f"t{i:04d}": i for i in range(1024)}, unk_token="t0000"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    tok.save(str(model_dir / "tokenizer.json"))
+    (model_dir / "tokenizer_config.json").write_text(json.dumps({"tokenizer_class": "PreTrainedTokenizerFast", "eos_token": "t0007", "unk_token": "t0000"}))
+    llm = LLM(str(model_dir), max_num_batched_tokens=512, max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=16,
+              chunked_prefill=True, enforce_eager=True)
+    try:
+        llm.model_runner.load_weights(hf_named(w, shape))
+        assert llm.tokenizer is not None and llm.config.eos == 7
+        ids = prompts_of([12, 40], seed=9)
+        texts = [" ".join(f"t{i:04d}" for i in p) for p in ids]      # fixed-width names: no token is a prefix of another
+        outs = llm.generate(texts, SamplingParams(temperature=1e-9, max_tokens=5, ignore_eos=True), use_tqdm=False)
+        for p, o in zip(ids, outs):
+            assert len(o["token_ids"]) == 5
+            assert o["text"].split() == [f"t{i:04d}" for i in o["token_ids"]]
+            check_teacher_forced(weights, p, o["token_ids"])
+        # eos: force it by making the request's first sampled id the eos id, then it must stop after one token
+        first = outs[0]["token_ids"][0]
+        llm.config.eos = llm.scheduler.eos = first
+        again = llm.generate(texts[:1], SamplingParams(temperature=1e-9, max_tokens=5), use_tqdm=False)
+        assert again[0]["token_ids"] == [first]
+    finally:
+        llm.exit()
