@@ -312,6 +312,24 @@ def test_attn_decode_fused_qkv_equals_sequence(ops, hq, hkv, splits):
     assert float(got[6].abs().max()) == 0.0
 
 
+def test_attn_decode_merge_kernels_agree(ops):
+    """The range merge has a few-rows and a many-rows kernel (more than 2048 output rows); they must give the same
+    bits for the same sequence: 8 sequences alone vs the same 8 at the front of a batch of 160."""
+    hq, hkv = 16, 8
+    lens8 = [1, 255, 256, 257, 1000, 64, 0, 700]
+    lens_k = lens8 + [300] * 152
+    b = len(lens_k)
+    q, kc, vc, bt, _, _ = _paged_case(91, [1] * b, lens_k, hq, hkv, num_pages=2 * b + 8)
+    ctx = torch.tensor(lens_k, dtype=torch.int32)
+    scale = 128 ** -0.5
+    for splits in (5, 16):
+        big = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=splits)
+        small = ops.attn_decode(dev(q[:8]), dev(kc), dev(vc), dev(ctx[:8]), dev(bt[:8]), scale, num_splits=splits)
+        assert_exact(big[:8], small.cpu())
+        ref = R.attention_decode(q[:16], kc, vc, ctx[:16], bt[:16], scale)
+        assert_close(big[:16], ref, 1.5e-2, 2e-2)
+
+
 def test_attn_decode_strided_q_long_context(ops):
     hq, hkv, d = 16, 8, 128
     lens_k = [8192, 3000]
