@@ -115,13 +115,14 @@ class Driver:
     def decode_step(self, seqs):
         for s in seqs:
             s.num_new_tokens = 1
-            self.grow(s, s.num_cached_tokens + 1)
+            if len(s.block_table) * PAGE <= s.num_cached_tokens:     # the new token starts a page
+                self.grow(s, s.num_cached_tokens + 1)
         toks, need = self.runner.run(seqs)
         toks = self.share_tokens(toks, len(seqs))
-        for s, t in zip(seqs, toks):
+        for s, t in zip(seqs, toks):                                  # ids arrive as Python ints
             s.num_cached_tokens += 1
             s.num_new_tokens = 0
-            s.append_token(int(t))
+            s.append_token(t)
 
 
 def collective_device():

@@ -4,6 +4,7 @@
 // Compiled with -ffp-contract=off so fp32 products and sums round separately, matching the
 // rounding points of the reference's eager arithmetic.
 #include "common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------ RMSNorm family
 // LPR lanes cooperate on one row (16 for head_dim-sized rows, 64 for hidden-sized rows);
@@ -188,7 +189,8 @@ static int32_t launch_rmsnorm(const bf16* x, int64_t xs, bf16* res, const bf16* 
         rmsnorm_kernel<16, 1, ADD, PARTIALS><<<nvh_cdiv(rows, 16), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 1024) {
         // decode-sized batches: one wave per workgroup, so a few hundred rows still reach every CU
-        if (PARTIALS && rows <= 64 && np >= 8)
+        static const bool no_wide = getenv("NVH_NORM_NO_WIDE") != nullptr;      // A/B switch for measurements
+        if (PARTIALS && rows <= 64 && np >= 8 && !no_wide)
             rmsnorm_kernel<64, 2, ADD, PARTIALS, 256, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
         else if (rows <= 1024)
             rmsnorm_kernel<64, 2, ADD, PARTIALS, 64><<<(unsigned)rows, 64, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
