@@ -182,7 +182,10 @@ class BlockManager:
         hashed (chained on their predecessor) so later arrivals can share them."""
         bs = self.block_size
         end = seq.num_cached_tokens + seq.num_new_tokens
-        for lo in range(seq.num_cached_blocks * bs, end, bs):
+        first = seq.num_cached_blocks
+        if first < len(seq.block_table) and end < (first + 1) * bs:
+            return                                           # the tokens fit the last resident page without filling it
+        for lo in range(first * bs, end, bs):
             tokens = seq[lo:min(lo + bs, end)]
             index = lo // bs
             block = self.blocks[seq.block_table[index]] if index < len(seq.block_table) else None

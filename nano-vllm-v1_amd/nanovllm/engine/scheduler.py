@@ -47,6 +47,7 @@ class Scheduler:
         """Running sequences in queue order.  When pages run out the NEWEST running sequence is pre-empted
         (possibly the one being considered, which ends the pass)."""
         bm = self.block_manager
+        bs = bm.block_size
         scheduled: list[Sequence] = []
         preempted = False
         i = 0
@@ -57,6 +58,14 @@ class Scheduler:
                 n = min(n, budget)
             n = min(n, self.max_model_len - 1 - seq.num_cached_tokens)
             assert n > 0
+            if n == 1 and 0 < seq.num_cached_tokens % bs < bs - 1:
+                # a decode token that stays inside its partly filled page: no page to take, none to hash
+                # (can_append is trivially true and may_append would do nothing)
+                seq.num_new_tokens = 1
+                scheduled.append(seq)
+                budget -= 1
+                i += 1
+                continue
             while not bm.can_append(seq, n) and len(self.running) > i:
                 self.preempt(self.running.pop())
                 preempted = True
