@@ -274,6 +274,14 @@ typedef struct {
     int64_t table_stride;
     int32_t max_seqlen_q, max_seqlen_k;
     int32_t mode, decode_splits;       /* decode_splits >= 1 */
+    /* Mixed steps (mode PAGED) whose first `decode_prefix` sequences have exactly one new token each (the running
+     * sequences of a serving step): their attention goes through the decode kernel (with `decode_splits` key
+     * ranges), the remaining sequences through the var-len kernel with the two arrays below = cu_seqlens of
+     * sequences decode_prefix.. rebased to start at 0, [batch - decode_prefix + 1] each.  The reference sends the
+     * whole mixed batch through one var-len call (layers/attention.py:236-248); one 64-row block per one-token
+     * sequence made that call half of the GPU time of a saturated serving run.  0 = no split. */
+    int64_t decode_prefix;
+    const int32_t *cu_seqlens_q_tail, *cu_seqlens_k_tail;
 } nvh_step;
 
 int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_tokens, int64_t batch, int32_t decode_splits);

@@ -64,9 +64,15 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
     if (t == 0) return NVH_OK;
     const int32_t dsplits = st->decode_splits < 1 ? 1 : st->decode_splits;
     NVH_REQUIRE(workspace && nvh_aligned16(workspace), NVH_EINVAL, "nvh_qwen3_forward: workspace missing or misaligned");
+    // one-token sequences at the head of a mixed step go through the decode kernel (one token = one row there)
+    const int64_t prefix = st->mode == NVH_MODE_PAGED ? st->decode_prefix : 0;
+    NVH_REQUIRE(prefix >= 0 && prefix <= b && prefix <= t, NVH_EINVAL, "nvh_qwen3_forward: decode_prefix %ld outside the batch", (long)prefix);
+    NVH_REQUIRE(prefix == 0 || (st->context_lens && st->slot_mapping && st->cu_seqlens_q_tail && st->cu_seqlens_k_tail &&
+                                md->k_cache && md->v_cache), NVH_EINVAL,
+                "nvh_qwen3_forward: decode_prefix needs a KV cache, context_lens, slot_mapping and the tail offsets");
     int32_t vsplits = 1;
-    if (st->mode != NVH_MODE_DECODE) {
-        vsplits = nvh_attn_varlen_suggest_splits(t, b, md->num_q_heads, md->num_kv_heads, st->max_seqlen_k);
+    if (st->mode != NVH_MODE_DECODE && b > prefix) {
+        vsplits = nvh_attn_varlen_suggest_splits(t - prefix, b - prefix, md->num_q_heads, md->num_kv_heads, st->max_seqlen_k);
         if (vsplits > kMaxVarlenSplits) vsplits = kMaxVarlenSplits;
     }
     Workspace w = carve(md, t, b, dsplits, kMaxVarlenSplits, (char*)workspace);
@@ -118,12 +124,22 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
                                           st->context_lens, st->block_tables, st->table_stride, b, hq, hkv, d, scale, w.attn,
                                           dsplits, w.decode_ws, stream));
         } else {
-            FWD(nvh_qknorm_rope_store(w.qkv, qkv_n, hq, hkv, md->q_norm[l], md->k_norm[l], md->eps, st->positions,
-                                      md->cos_sin, md->max_position, store ? kc : nullptr, store ? vc : nullptr,
-                                      store ? st->slot_mapping : nullptr, t, stream));
+            if (t > prefix)
+                FWD(nvh_qknorm_rope_store(w.qkv + prefix * qkv_n, qkv_n, hq, hkv, md->q_norm[l], md->k_norm[l], md->eps,
+                                          st->positions + prefix, md->cos_sin, md->max_position, store ? kc : nullptr,
+                                          store ? vc : nullptr, store ? st->slot_mapping + prefix : nullptr, t - prefix, stream));
             if (st->mode == NVH_MODE_DECODE) {
                 FWD(nvh_attn_decode(w.qkv, qkv_n, kc, vc, st->context_lens, st->block_tables, st->table_stride, b, hq, hkv,
                                     d, scale, w.attn, dsplits, w.decode_ws, stream));
+            } else if (prefix > 0) {
+                // (the qk-norm / rope / store launch above covered only the tokens past the one-token sequences)
+                FWD(nvh_attn_decode_fused_qkv(w.qkv, qkv_n, md->q_norm[l], md->k_norm[l], md->eps, st->positions, md->cos_sin, kc, vc,
+                                              st->context_lens, st->block_tables, st->table_stride, prefix, hq, hkv, d, scale, w.attn,
+                                              dsplits, w.decode_ws, stream));
+                if (b > prefix)
+                    FWD(nvh_attn_varlen(w.qkv + prefix * qkv_n, qkv_n, kc, vc, kvsz, st->cu_seqlens_q_tail, st->cu_seqlens_k_tail,
+                                        st->block_tables + prefix * st->table_stride, st->table_stride, b - prefix, st->max_seqlen_q,
+                                        st->max_seqlen_k, t - prefix, hq, hkv, d, scale, w.attn + prefix * qsz, vsplits, w.varlen_ws, stream));
             } else if (st->mode == NVH_MODE_PAGED) {
                 FWD(nvh_attn_varlen(w.qkv, qkv_n, kc, vc, kvsz, st->cu_seqlens_q, st->cu_seqlens_k, st->block_tables,
                                     st->table_stride, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));

@@ -160,6 +160,7 @@ class ModelRunner:
         self.device = torch.device("cuda", device_index)
         _hip.check(_hip.lib().nvh_device_check(device_index), "nvh_device_check")
 
+        self.split_mixed = os.environ.get("NANOVLLM_SPLIT_MIXED", "1") != "0"     # A/B switch: decode prefix of mixed steps
         self.comm = None
         if self.world_size > 1:
             # staging: the widest all-reduce (a full token budget of hidden rows) or logits gather (every sequence)
@@ -328,7 +329,21 @@ class ModelRunner:
         if self.rank == 0:
             temps = np.fromiter((s.temperature for s in seqs), dtype=np.float32, count=len(seqs))
             arrays["temperatures"] = temps[fb["need"]] if fb["need"].size else temps
+        # Mixed step: the running sequences come first with one token each; the native executor sends that prefix
+        # through the decode kernel and needs the remaining sequences' offsets rebased to zero.
+        prefix = 0
+        if self.native is not None and fb["block_tables"] is not None and fb["max_seqlen_q"] > 1 and self.split_mixed:
+            new = np.diff(fb["cu_seqlens_q"])
+            other = np.flatnonzero(new != 1)
+            prefix = int(other[0]) if other.size else len(new)
+            if prefix >= 8:
+                arrays["cu_seqlens_q_tail"] = fb["cu_seqlens_q"][prefix:] - fb["cu_seqlens_q"][prefix]
+                arrays["cu_seqlens_k_tail"] = fb["cu_seqlens_k"][prefix:] - fb["cu_seqlens_k"][prefix]
+            else:
+                prefix = 0
+        fb["decode_prefix"] = prefix
         d = self.staging.upload(arrays)
+        fb["tails"] = (d.get("cu_seqlens_q_tail"), d.get("cu_seqlens_k_tail"))
         set_context(d["cu_seqlens_q"], d["cu_seqlens_k"], fb["max_seqlen_q"], fb["max_seqlen_k"], d["slot_mapping"],
                     d["context_lens"], d.get("block_tables"), d["need"])
         return d["input_ids"], d["positions"], d.get("temperatures"), fb
@@ -351,10 +366,16 @@ class ModelRunner:
             splits = self.decode_splits(bs)
         else:
             mode, splits = MODE_PAGED, 1
+        prefix = fb.get("decode_prefix", 0) if mode == MODE_PAGED else 0
+        tails = fb.get("tails", (None, None))
+        if prefix:
+            hkv = self.model.model.layers[0].self_attn.num_kv_heads
+            splits = ops.suggest_decode_splits(prefix, hkv, int(fb["context_lens"][:prefix].max()))
         return self.native.forward(input_ids, positions, mode=mode, batch=bs, cu_seqlens_q=ctx.cu_seqlens_q,
                                    cu_seqlens_k=ctx.cu_seqlens_k, max_seqlen_q=fb["max_seqlen_q"],
                                    max_seqlen_k=fb["max_seqlen_k"], slot_mapping=ctx.slot_mapping,
-                                   context_lens=ctx.context_lens, block_tables=ctx.block_tables, decode_splits=splits)
+                                   context_lens=ctx.context_lens, block_tables=ctx.block_tables, decode_splits=splits,
+                                   decode_prefix=prefix, cu_seqlens_q_tail=tails[0], cu_seqlens_k_tail=tails[1])
 
     def decode_buckets(self) -> list[int]:
         max_bs = min(self.config.max_num_seqs, 512)

@@ -29,7 +29,8 @@ class ModelDesc(C.Structure):
 class StepDesc(C.Structure):
     _fields_ = [("num_tokens", i64), ("batch", i64), ("input_ids", vp), ("positions", vp), ("cu_seqlens_q", vp),
                 ("cu_seqlens_k", vp), ("slot_mapping", vp), ("context_lens", vp), ("block_tables", vp),
-                ("table_stride", i64), ("max_seqlen_q", i32), ("max_seqlen_k", i32), ("mode", i32), ("decode_splits", i32)]
+                ("table_stride", i64), ("max_seqlen_q", i32), ("max_seqlen_k", i32), ("mode", i32), ("decode_splits", i32),
+                ("decode_prefix", i64), ("cu_seqlens_q_tail", vp), ("cu_seqlens_k_tail", vp)]
 
 
 def _ptr(t):
@@ -94,7 +95,8 @@ class NativeQwen3:
         self.device = m.lm_head.weight.device
 
     def forward(self, input_ids, positions, *, mode, batch, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0,
-                max_seqlen_k=0, slot_mapping=None, context_lens=None, block_tables=None, decode_splits=1):
+                max_seqlen_k=0, slot_mapping=None, context_lens=None, block_tables=None, decode_splits=1,
+                decode_prefix=0, cu_seqlens_q_tail=None, cu_seqlens_k_tail=None):
         t = input_ids.numel()
         st = StepDesc()
         st.num_tokens, st.batch = t, batch
@@ -104,6 +106,9 @@ class NativeQwen3:
         st.block_tables = _ptr(block_tables)
         st.table_stride = block_tables.stride(0) if block_tables is not None else 0
         st.max_seqlen_q, st.max_seqlen_k, st.mode, st.decode_splits = max_seqlen_q, max_seqlen_k, mode, max(1, decode_splits)
+        if decode_prefix:
+            st.decode_prefix = decode_prefix
+            st.cu_seqlens_q_tail, st.cu_seqlens_k_tail = _ptr(cu_seqlens_q_tail), _ptr(cu_seqlens_k_tail)
         nbytes = self.lib.nvh_qwen3_workspace_bytes(C.byref(self.desc), t, batch, st.decode_splits)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         out = torch.empty(t, self.desc.hidden, dtype=torch.bfloat16, device=self.device)

@@ -216,3 +216,66 @@ def test_native_executor_equals_operator_modules(eager, modules):
         outs.append(got)
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+def test_mixed_step_decode_prefix_matches_oracle_and_unsplit_path():
+    """A serving-shaped step: ten running sequences with one token each (contexts that sit on, before and after page
+    boundaries), then a continuing chunk and a fresh prompt.  The native executor sends the one-token prefix through
+    the decode kernel and the rest through the var-len kernel; logits must match the oracle, and the other route
+    (everything through the var-len kernel) within the same tolerance, with the same K/V pages."""
+    import os
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+    shape = M.ModelShape(**TINY)
+    weights = M.random_weights(shape, seed=0, std=0.05)
+    g = torch.Generator().manual_seed(77)
+    ctxs = [2, 17, 255, 256, 257, 300, 511, 512, 513, 40]              # context after the new token
+    decode = [torch.randint(0, 1024, (n,), generator=g).tolist() for n in ctxs]
+    chunk = torch.randint(0, 1024, (400,), generator=g).tolist()         # 256 cached, 100 scheduled now
+    fresh = torch.randint(0, 1024, (70,), generator=g).tolist()
+    tables, page = [], 0
+    for n in ctxs + [356, 70]:
+        nb = (n + 255) // 256
+        tables.append(list(range(page, page + nb)))
+        page += nb
+    results = {}
+    for split in ("1", "0"):
+        os.environ["NANOVLLM_NATIVE"] = "1"
+        os.environ["NANOVLLM_SPLIT_MIXED"] = split
+        cfg = Config(TINY_DIR, max_num_batched_tokens=1024, max_num_seqs=16, max_model_len=2048, enforce_eager=True,
+                     num_kvcache_blocks=page + 1, chunked_prefill=True)
+        runner = ModelRunner(cfg, 0, [])
+        try:
+            runner.load_weights(hf_named(weights, shape))
+            runner.kv_cache.zero_()
+            oracle = M.RefRunner(shape, weights, page + 1)
+            # fill the caches: every decode sequence but its last token, and the first 256 tokens of the chunked prompt
+            warm = [(d[:-1], t) for d, t in zip(decode, tables) if len(d) > 1] + [(chunk[:256], tables[10])]
+            for toks, tb in warm:
+                tb = tb[:(len(toks) + 255) // 256]                         # the pages those tokens need, no more
+                runner.forward_logits([seq(toks, 0, len(toks), tb)])
+                oracle.run([M.SeqState(list(toks), 0, len(toks), list(tb))])
+            batch = [seq(d, len(d) - 1, 1, t) for d, t in zip(decode, tables)]
+            batch += [seq(chunk, 256, 100, tables[10]), seq(fresh, 0, 70, tables[11])]
+            fb_prefix = []
+            orig = runner.native.forward
+            runner.native.forward = lambda *a, **k: (fb_prefix.append(k.get("decode_prefix", 0)), orig(*a, **k))[1]
+            logits, _, need = runner.forward_logits(batch)
+            assert fb_prefix == [10 if split == "1" else 0]
+            assert need.tolist() == list(range(10)) + [11]                 # the chunk does not reach its prompt's end
+            ob = [M.SeqState(list(d), len(d) - 1, 1, list(t)) for d, t in zip(decode, tables)]
+            ob += [M.SeqState(list(chunk), 256, 100, list(tables[10])), M.SeqState(list(fresh), 0, 70, list(tables[11]))]
+            ol, _ = oracle.run(ob)
+            close(logits, ol)
+            got = logits.float().cpu()
+            top = got.max(-1).values
+            picked = got.gather(1, ol.float().argmax(-1, keepdim=True)).squeeze(1)
+            assert bool((picked >= top - (3e-2 + 2e-2 * top.abs())).all())  # the oracle's greedy id wins, up to bf16 ties
+            results[split] = (logits.cpu(), runner.kv_cache.cpu().clone())
+        finally:
+            runner.exit()
+            os.environ.pop("NANOVLLM_SPLIT_MIXED", None)
+    close(results["1"][0], results["0"][0])
+    kv1, kv0 = results["1"][1], results["0"][1]                            # [2, layers, pages, 256, kv heads, 128]
+    assert torch.equal(kv1[:, 0], kv0[:, 0])                               # first layer: the same K/V rows, bit for bit
+    close(kv1, kv0)                                                        # deeper layers inherit the attention outputs' last bits
