@@ -245,7 +245,7 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
     static const int force = getenv("NVH_GEMM_FORCE_TILE") ? atoi(getenv("NVH_GEMM_FORCE_TILE")) : -1;   // tuning switch
     if (force >= T16x128 && force <= T256x128) return (Tile)force;
-    if (M <= 64) return T64x128;
+    if (M <= 64) return nvh_cdiv(N, 128) * split_k >= 384 ? T64x128 : T64x64;   // 33..64 rows: enough workgroups first
     // very wide outputs with few rows (LM head at decode batch 256): all rows in one tile, so every weight row is
     // fetched once; three stages, one workgroup per CU
     static const bool no256 = getenv("NVH_GEMM_NO_256") != nullptr;

@@ -10,7 +10,7 @@ from bench_kernels import timeit
 BF = torch.bfloat16
 shapes = [("qkv", 7168, 5120), ("o", 5120, 5120), ("gate_up", 34816, 5120), ("down", 5120, 17408)]
 print(f"{'op':>8} {'M':>4} {'split':>5} {'us':>8} {'W GB/s':>8}")
-for m in (1, 8, 32, 64, 256):
+for m in ([int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 256]):
     tot = 0.0
     for name, n, k in shapes:
         copies = max(3, (700 << 20) // (n * k * 2) + 1)
