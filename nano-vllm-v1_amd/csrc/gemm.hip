@@ -270,9 +270,11 @@ extern "C" int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K) {
     if (t == T32x32) t = T32x128;                              // 17..32 rows: split on the 128-row tile's terms
     const bool skinny = t == T16x32;
     const int64_t tiles = nvh_cdiv(N, tile_bn(t)) * nvh_cdiv(M, tile_bm(t));
-    const int64_t want = skinny ? 768 : 256;
     if (tiles >= (skinny ? 512 : 160)) return 1;
-    int64_t s = nvh_cdiv(want, tiles);
+    // two-wave decode tiles: three workgroups fit a CU (768 slots).  Stay inside ONE round of workgroups: a grid a
+    // little over a multiple of 768 pays a whole workgroup lifetime for its last few tiles (160 tiles: 3 slabs
+    // 10.5 us, 4 slabs 11.1 us, 5 slabs = 800 workgroups 13.3 us).
+    int64_t s = skinny ? (768 * 4 / 5) / tiles : nvh_cdiv(256, tiles);
     const int64_t kmax = K / 256 > 1 ? K / 256 : 1;
     if (s > kmax) s = kmax;
     if (s > 16) s = 16;
@@ -312,11 +314,11 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
     if (tile == T64x64 && s64 == 8) { launch_gemm<64, 64, 2, 2, 8>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
     switch (tile) {
         case T16x32:
-            if (a.swiglu) launch_gemm<32, 32, 1, 2, 8>(a);      // gate and up tile of a pair in the same wave
+            if (a.swiglu) launch_gemm<32, 32, 1, 2, 6>(a);      // gate and up tile of a pair in the same wave; 6 stages = 48 KB: three workgroups per CU
             else launch_gemm<16, 32, 2, 1, 8>(a);
             break;
         case T32x32:
-            if (a.swiglu) launch_gemm<32, 32, 1, 2, 8>(a);
+            if (a.swiglu) launch_gemm<32, 32, 1, 2, 6>(a);
             else launch_gemm<32, 32, 2, 1, 8>(a);
             break;
         case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;

@@ -20,6 +20,13 @@ inline int64_t align256(int64_t n) { return (n + 255) & ~int64_t(255); }
 
 int32_t split_for(int64_t m, int64_t n, int64_t k) { return nvh_gemm_suggest_split_k(m, n, k); }
 
+// The QKV projection has no consumer that sums split-K slabs, so splitting it costs a reduce launch.  Worth it only
+// for a few rows over a long K with too few column tiles to occupy the chip (Qwen3-14B at decode: 224 tiles,
+// 21.3 us unsplit, 15.9 us as two slabs + reduce); never for K = 1024 (the 0.6B model), where a tile lives 4 us.
+int32_t split_for_qkv(int64_t m, int64_t n, int64_t k) {
+    return (m <= 16 && k >= 4096 && (n + 31) / 32 <= 300) ? 2 : 1;
+}
+
 Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_splits, int32_t varlen_splits, char* base) {
     const int64_t h = md->hidden, d = md->head_dim;
     const int64_t qsz = (int64_t)md->num_q_heads * d, kvsz = (int64_t)md->num_kv_heads * d;
@@ -35,7 +42,10 @@ Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_
     w.act = (bf16*)take(t * md->inter * 2);
     const int64_t so = split_for(t, h, qsz), sd = split_for(t, h, md->inter);
     const int64_t smax = so > sd ? so : sd;
-    w.slabs = (float*)take(smax > 1 ? smax * t * h * 4 : 0);
+    const int64_t sq = split_for_qkv(t, qsz + 2 * kvsz, h);
+    const int64_t slab_floats = (smax > 1 ? smax * t * h : 0) > (sq > 1 ? sq * t * (qsz + 2 * kvsz) : 0)
+                                    ? (smax > 1 ? smax * t * h : 0) : (sq > 1 ? sq * t * (qsz + 2 * kvsz) : 0);
+    w.slabs = (float*)take(slab_floats * 4);
     w.decode_ws = take(nvh_attn_decode_workspace_bytes(b, md->num_q_heads, d, decode_splits));
     w.varlen_ws = take(nvh_attn_varlen_workspace_bytes(t, md->num_q_heads, d, varlen_splits));
     w.total = off;
@@ -86,6 +96,7 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
     const float scale = 1.0f / sqrtf((float)d);
     // partial sums of different ranks meet in bf16: no split-K slab hand-off under tensor parallelism
     const int32_t so = md->comm ? 1 : split_for(t, h, qsz), sd = md->comm ? 1 : split_for(t, h, md->inter);
+    const int32_t sq = split_for_qkv(t, qkv_n, h);
 
     nvh_comm* comm = md->comm;
     bf16* proj_out = w.y;               // where the row-parallel projections write their bf16 result
@@ -113,7 +124,12 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
                                 pending_slabs ? w.slabs : nullptr, pending_count, stream));
         }
         // ---- attention block
-        FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, w.qkv, qkv_n, t, qkv_n, h, 1, nullptr, stream));
+        if (sq > 1) {
+            FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, nullptr, qkv_n, t, qkv_n, h, sq, w.slabs, stream));
+            FWD(nvh_splitk_reduce(w.slabs, sq, nullptr, w.qkv, qkv_n, t, qkv_n, stream));
+        } else {
+            FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, w.qkv, qkv_n, t, qkv_n, h, 1, nullptr, stream));
+        }
         void* kc = md->k_cache ? md->k_cache[l] : nullptr;
         void* vc = md->v_cache ? md->v_cache[l] : nullptr;
         const bool store = kc && vc && st->slot_mapping;

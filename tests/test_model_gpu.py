@@ -279,3 +279,44 @@ def test_mixed_step_decode_prefix_matches_oracle_and_unsplit_path():
     kv1, kv0 = results["1"][1], results["0"][1]                            # [2, layers, pages, 256, kv heads, 128]
     assert torch.equal(kv1[:, 0], kv0[:, 0])                               # first layer: the same K/V rows, bit for bit
     close(kv1, kv0)                                                        # deeper layers inherit the attention outputs' last bits
+
+
+def test_wide_hidden_decode_uses_split_qkv_and_matches_oracle(tmp_path):
+    """hidden_size 4096: at a few rows the native executor splits the QKV projection over K and reduces the slabs
+    (and sums 3+ slabs of the O / down projections inside the norms).  Prefill then three decode steps, two
+    sequences, against the CPU oracle."""
+    import json
+    import os
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+    wide = dict(TINY, hidden_size=4096, num_hidden_layers=1, num_attention_heads=8, num_key_value_heads=2)
+    cfg_json = json.load(open(os.path.join(TINY_DIR, "config.json")))
+    cfg_json.update(wide)
+    d = tmp_path / "wide"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps(cfg_json))
+    shape = M.ModelShape(**wide)
+    weights = M.random_weights(shape, seed=3, std=0.02)
+    os.environ["NANOVLLM_NATIVE"] = "1"
+    runner = ModelRunner(Config(str(d), max_num_batched_tokens=512, max_num_seqs=8, max_model_len=1024, enforce_eager=True,
+                                num_kvcache_blocks=4, chunked_prefill=True), 0, [])
+    try:
+        runner.load_weights(hf_named(weights, shape))
+        oracle = M.RefRunner(shape, weights, 4)
+        g = torch.Generator().manual_seed(5)
+        prompts = [torch.randint(0, 1024, (n,), generator=g).tolist() for n in (9, 40)]
+        seqs = [seq(p, 0, len(p), [i]) for i, p in enumerate(prompts)]
+        states = [M.SeqState(list(p), 0, len(p), [i]) for i, p in enumerate(prompts)]
+        for step in range(4):
+            logits, _, need = runner.forward_logits(seqs)
+            ref, _ = oracle.run(states)
+            close(logits, ref)
+            toks = ref.float().argmax(-1).tolist()                          # both sides continue with the oracle's ids
+            for s, st, t in zip(seqs, states, toks):
+                s.num_cached_tokens += s.num_new_tokens
+                s.append_token(t)
+                s.num_new_tokens = 1
+                st.token_ids.append(t)
+                st.num_cached_tokens, st.num_new_tokens = s.num_cached_tokens, 1
+    finally:
+        runner.exit()
