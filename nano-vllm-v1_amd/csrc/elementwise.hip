@@ -180,6 +180,88 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
     }
 }
 
+// Wide rows (hidden sizes above 1024): one 256-thread workgroup per row, thread t owns the 16-byte chunks
+// t, t + 256, ..  The one-wave-per-row kernel above leaves a decode batch of 8 rows of 5120 on 8 waves of the whole
+// chip (17 us per call at 3 split-K slabs); here the same call is 4 waves per row with a quarter of the loads each.
+// Same arithmetic per element (slab p -> partial sum p mod 4, total (s0 + s1) + (s2 + s3), one bf16 rounding);
+// the sum of squares is reduced per wave, then (w0 + w1) + (w2 + w3).
+template <int MAXC, bool ADD, bool PARTIALS>
+__global__ __launch_bounds__(256) void rmsnorm_wide_kernel(
+    const bf16* __restrict__ x, int64_t x_stride, bf16* __restrict__ residual, const bf16* __restrict__ w,
+    bf16* __restrict__ y, int64_t y_stride, int64_t rows, int dim, float eps, const float* __restrict__ partials,
+    int num_partials) {
+    __shared__ float wave_ss[4];
+    const int64_t r = blockIdx.x;
+    const int nchunk = dim >> 3;
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nchunk) {
+            float xv[8];
+            if constexpr (PARTIALS) {
+                float acc[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
+                }
+                const float* src0 = partials + r * (int64_t)dim + c * 8;
+                const int64_t slab = rows * (int64_t)dim;
+                for (int p = 0; p < num_partials; p += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (p + u < num_partials) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab);
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { acc[u][j] += a[j]; acc[u][4 + j] += b[j]; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = bf2f(f2bf((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])));
+            } else {
+                bf16x8 t = *reinterpret_cast<const bf16x8*>(x + r * x_stride + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = bf2f(t[j]);
+            }
+            if constexpr (ADD) {
+                bf16x8 t = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + c * 8);
+                bf16x8 nr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xv[j] = xv[j] + bf2f(t[j]);
+                    nr[j] = f2bf(xv[j]);
+                }
+                *reinterpret_cast<bf16x8*>(residual + r * (int64_t)dim + c * 8) = nr;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = xv[j];
+                ss += xv[j] * xv[j];
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) wave_ss[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    ss = (wave_ss[0] + wave_ss[1]) + (wave_ss[2] + wave_ss[3]);
+    const float inv = 1.0f / sqrtf(ss / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nchunk) {
+            bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(v[i][j] * inv)) * bf2f(wv[j]));
+            *reinterpret_cast<bf16x8*>(y + r * y_stride + c * 8) = o;
+        }
+    }
+}
+
 template <bool ADD, bool PARTIALS>
 static int32_t launch_rmsnorm(const bf16* x, int64_t xs, bf16* res, const bf16* w, bf16* y, int64_t ys,
                               int64_t rows, int64_t dim, float eps, const float* partials, int np,
@@ -196,10 +278,12 @@ static int32_t launch_rmsnorm(const bf16* x, int64_t xs, bf16* res, const bf16* 
             rmsnorm_kernel<64, 2, ADD, PARTIALS, 64><<<(unsigned)rows, 64, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
         else
             rmsnorm_kernel<64, 2, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+    } else if (dim <= 2048) {
+        rmsnorm_wide_kernel<1, ADD, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 4096) {
-        rmsnorm_kernel<64, 8, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        rmsnorm_wide_kernel<2, ADD, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else {
-        rmsnorm_kernel<64, 16, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        rmsnorm_wide_kernel<4, ADD, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     }
     NVH_CHECK_LAUNCH("rmsnorm");
     return NVH_OK;
