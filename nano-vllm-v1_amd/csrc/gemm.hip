@@ -241,7 +241,8 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     static const bool no_skinny = getenv("NVH_GEMM_NO_SKINNY") != nullptr;
     const bool narrow = nvh_cdiv(N, 128) * split_k < 384 && !no_skinny;
     if (M <= 16) return narrow ? T16x32 : T16x128;
-    if (M <= 32) return (narrow && split_k == 1) ? T32x32 : T32x128;      // with split-K the 128-row tile measured faster
+    static const bool m32_skinny = getenv("NVH_GEMM_M32_SKINNY") != nullptr;   // tuning switch
+    if (M <= 32) return (narrow && (split_k == 1 || m32_skinny)) ? T32x32 : T32x128;      // with split-K the 128-row tile measured faster
     auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
     static const int force = getenv("NVH_GEMM_FORCE_TILE") ? atoi(getenv("NVH_GEMM_FORCE_TILE")) : -1;   // tuning switch
     if (force >= T16x128 && force <= T256x128) return (Tile)force;

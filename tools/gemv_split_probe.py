@@ -4,7 +4,7 @@ import torch
 from nanovllm import ops
 from bench_kernels import timeit
 BF = torch.bfloat16
-for m in (1, 8):
+for m in ([int(a) for a in sys.argv[1:]] or [1, 8]):
     for name, n, k in (("qkv", 7168, 5120), ("o", 5120, 5120), ("down", 5120, 17408)):
         copies = max(3, (700 << 20) // (n * k * 2) + 1)
         x = torch.randn(m, k, device="cuda").to(BF)
