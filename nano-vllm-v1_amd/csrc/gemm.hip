@@ -264,22 +264,60 @@ extern "C" int64_t nvh_gemm_workspace_bytes(int64_t M, int64_t N, int32_t split_
     return split_k > 1 ? (int64_t)split_k * M * N * (int64_t)sizeof(float) : 0;
 }
 
+namespace {
+// Workgroups of a tile that fit one CU (LDS: stages x (BM + BN) x 128 B of 160 KB).
+int tile_residents(Tile t) {
+    switch (t) {
+        case T16x32: case T32x32: return 3;
+        case T16x128: case T32x128: case T64x64: case T128x128: return 2;
+        default: return 1;                                     // T64x128, T128x64, T256x128
+    }
+}
+// Time model of one GEMM launch with `s` K-slabs, in microseconds.  These kernels are bound by the L2 -> LDS fill
+// (about 50 GB/s per CU, shared by the workgroups resident on it), so a round of workgroups costs
+// (k-tiles per slab + fixed part) x tile bytes x residents / fill rate, and a grid takes a whole number of rounds:
+// 320 workgroups on 256 slots cost two rounds.  Slabs add their write and the consumer's read.  It ranks the
+// measured split counts of the 14B projections at 256..1024 rows in the measured order.
+double splitk_estimate_us(int64_t M, int64_t N, int64_t K, int s) {
+    const Tile t = pick_tile(M, N, s);
+    const int64_t wgs = nvh_cdiv(M, tile_bm(t)) * nvh_cdiv(N, tile_bn(t)) * s;
+    int64_t res = nvh_cdiv(wgs, 256);
+    if (res > tile_residents(t)) res = tile_residents(t);
+    const int64_t rounds = nvh_cdiv(wgs, 256 * res);
+    const double ktiles = (double)nvh_cdiv(nvh_cdiv(K, BK), s) + 6.0;
+    const double tile_bytes = (double)(tile_bm(t) + tile_bn(t)) * 128.0;
+    double us = (double)rounds * ktiles * tile_bytes * (double)res / 50000.0;
+    if (s > 1) us += 2.0 * (double)s * (double)M * (double)N * 4.0 / 5.0e6;
+    return us;
+}
+}  // namespace
+
 extern "C" int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K) {
-    // Split only when even the smallest tile leaves most CUs idle: enough workgroups for 256 CUs (three rounds of
-    // the two-wave decode tiles, of which three fit a CU), at least 4 k-tiles (256 k) per split, at most 16 slabs.
-    Tile t = pick_tile(M, N, 1);
-    if (t == T32x32) t = T32x128;                              // 17..32 rows: split on the 128-row tile's terms
-    const bool skinny = t == T16x32;
-    const int64_t tiles = nvh_cdiv(N, tile_bn(t)) * nvh_cdiv(M, tile_bm(t));
-    if (tiles >= (skinny ? 512 : 160)) return 1;
-    // two-wave decode tiles: three workgroups fit a CU (768 slots).  Stay inside ONE round of workgroups: a grid a
-    // little over a multiple of 768 pays a whole workgroup lifetime for its last few tiles (160 tiles: 3 slabs
-    // 10.5 us, 4 slabs 11.1 us, 5 slabs = 800 workgroups 13.3 us).
-    int64_t s = skinny ? (768 * 4 / 5) / tiles : nvh_cdiv(256, tiles);
+    // at least 4 k-tiles (256 k) per slab, at most 16 slabs
     const int64_t kmax = K / 256 > 1 ? K / 256 : 1;
-    if (s > kmax) s = kmax;
-    if (s > 16) s = 16;
-    return (int32_t)(s < 1 ? 1 : s);
+    Tile t = pick_tile(M, N, 1);
+    if (t == T16x32) {
+        // two-wave decode tiles: three workgroups fit a CU (768 slots).  Stay inside ONE round of workgroups: a grid
+        // a little over a multiple of 768 pays a whole workgroup lifetime for its last few tiles (160 tiles: 3 slabs
+        // 10.5 us, 4 slabs 11.1 us, 5 slabs = 800 workgroups 13.3 us).
+        const int64_t tiles = nvh_cdiv(N, 32) * nvh_cdiv(M, 16);
+        if (tiles >= 512) return 1;
+        int64_t s = (768 * 4 / 5) / tiles;
+        if (s > kmax) s = kmax;
+        if (s > 16) s = 16;
+        return (int32_t)(s < 1 ? 1 : s);
+    }
+    // everything else: the slab count the time model likes best; a larger count has to win by 5 %
+    int best = 1;
+    double best_us = splitk_estimate_us(M, N, K, 1);
+    for (int s = 2; s <= 8 && s <= kmax; ++s) {
+        const double us = splitk_estimate_us(M, N, K, s);
+        if (us < 0.95 * best_us) {
+            best = s;
+            best_us = us;
+        }
+    }
+    return best;
 }
 
 extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const void* w, const void* bias, void* y,

@@ -17,7 +17,8 @@ from nanovllm.engine.sequence import Sequence  # noqa: E402
 t = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 prefix = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-cfg = Config(str(ROOT / "nano-vllm-v1_amd" / "model_configs" / "qwen3-0.6b"), max_num_batched_tokens=max(t, 1024), max_num_seqs=8,
+import os
+cfg = Config(str(ROOT / "nano-vllm-v1_amd" / "model_configs" / os.environ.get("NANOVLLM_PROBE_MODEL", "qwen3-0.6b")), max_num_batched_tokens=max(t, 1024), max_num_seqs=8,
              max_model_len=16384, enforce_eager=True, chunked_prefill=True, num_kvcache_blocks=64 * steps + 64)
 runner = ModelRunner(cfg, 0, [])
 g = torch.Generator().manual_seed(0)
