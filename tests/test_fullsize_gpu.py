@@ -1,0 +1,126 @@
+"""Qwen3-0.6B at its real shape (28 layers, hidden 1024, vocabulary 151936; synthetic weights) is too large for the
+CPU oracle to follow in test time, so these tests check properties that do not depend on size: a prompt gives the
+same logits whether it is prefilled at once or in chunks, a captured decode graph equals the eager step bit for
+bit, the order of the sequences in a batch does not change a single bit of any row, and a sequence that borrows
+the pages of a shared prefix sees the logits of one that computed it itself."""
+import os
+from pathlib import Path
+
+import pytest
+import torch
+
+from test_model_gpu import seq
+
+pytestmark = pytest.mark.gpu
+MODEL = str(Path(__file__).resolve().parent.parent / "nano-vllm-v1_amd" / "model_configs" / "qwen3-0.6b")
+
+
+def make(enforce_eager, budget=1024, pages=40):
+    os.environ["NANOVLLM_NATIVE"] = "1"
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+    cfg = Config(MODEL, max_num_batched_tokens=budget, max_num_seqs=16, max_model_len=4096, enforce_eager=enforce_eager,
+                 num_kvcache_blocks=pages, chunked_prefill=True)
+    return ModelRunner(cfg, 0, [])
+
+
+def close(a, b, atol=6e-2, rtol=3e-2):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    assert bool((err <= atol + rtol * b.abs()).all()), f"max err {float(err.max()):.4g}"
+
+
+def greedy_agrees(a, b, atol=6e-2, rtol=3e-2):
+    """b's greedy id scores within tolerance of a's best in a (exact bf16 ties may resolve either way)."""
+    a, b = a.float().cpu(), b.float().cpu()
+    top = a.max(-1).values
+    picked = a.gather(1, b.argmax(-1, keepdim=True)).squeeze(1)
+    assert bool((picked >= top - (atol + rtol * top.abs())).all())
+
+
+@pytest.fixture(scope="module")
+def eager():
+    r = make(True, budget=2048)
+    yield r
+    r.exit()
+
+
+def prompts(lengths, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 10000, (n,), generator=g).tolist() for n in lengths]
+
+
+def test_chunked_prefill_equals_one_pass(eager):
+    p = prompts([1500], 1)[0]
+    table = [0, 1, 2, 3, 4, 5]
+    whole, _, need = eager.forward_logits([seq(p, 0, len(p), table)])
+    assert need.tolist() == [0]
+    s = seq(p, 0, 0, table)
+    logits = None
+    for n in (700, 300, 500):                                   # page-crossing chunks
+        s.num_new_tokens = n
+        logits, _, _ = eager.forward_logits([s])
+        s.num_cached_tokens += n
+    close(logits, whole)
+    greedy_agrees(logits, whole)
+
+
+def test_batch_order_does_not_change_any_row(eager):
+    ps = prompts([300, 17, 600, 129, 256], 2)
+    tables = [[6, 7], [8], [9, 10, 11], [12], [13, 14]]
+    first = [seq(p, 0, len(p), t) for p, t in zip(ps, tables)]
+    logits, _, _ = eager.forward_logits(first)
+    toks = logits.float().argmax(-1).tolist()
+
+    def decode_batch(order):
+        batch = []
+        for i in order:
+            batch.append(seq(ps[i] + [toks[i]], len(ps[i]), 1, tables[i]))
+        out, _, _ = eager.forward_logits(batch)
+        return out.cpu()
+
+    for t, p in zip(tables, ps):                               # every table must hold position len(p)
+        assert len(t) * 256 > len(p)
+    a = decode_batch([0, 1, 2, 3, 4])
+    order = [3, 0, 4, 2, 1]
+    b = decode_batch(order)
+    for row, i in enumerate(order):
+        assert torch.equal(b[row], a[i]), f"sequence {i} changed with its position in the batch"
+
+
+def test_graph_replay_equals_eager_at_full_size(eager):
+    graphed = make(False, budget=1024, pages=24)
+    try:
+        ps = prompts([200, 513, 40], 3)
+        tables = [[0], [1, 2, 3], [4]]
+        outs = []
+        for r in (eager, graphed):
+            seqs = [seq(p, 0, len(p), t) for p, t in zip(ps, tables)]
+            logits, _, _ = r.forward_logits(seqs)
+            steps = []
+            for _ in range(3):
+                for s, t in zip(seqs, logits.float().argmax(-1).tolist()):
+                    s.num_cached_tokens += s.num_new_tokens
+                    s.append_token(t)
+                    s.num_new_tokens = 1
+                logits, _, _ = r.forward_logits(seqs)
+                steps.append(logits.cpu())
+            outs.append(torch.stack(steps))
+        assert graphed.graphs
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        graphed.exit()
+
+
+def test_shared_prefix_pages_give_the_same_logits(eager):
+    shared = prompts([512], 4)[0]
+    tail_a, tail_b = prompts([40, 90], 5)
+    a = seq(shared + tail_a, 0, 552, [20, 21, 22])
+    eager.forward_logits([a])                                   # fills pages 20, 21 with the shared prefix
+    own = seq(shared + tail_b, 0, 602, [23, 24, 25])            # computes the prefix itself
+    borrowed = seq(shared + tail_b, 512, 90, [20, 21, 26])      # prefix hit: only the tail is scheduled
+    lo, _, _ = eager.forward_logits([own])
+    lb, _, need = eager.forward_logits([borrowed])
+    assert need.tolist() == [0]
+    close(lb, lo)
+    greedy_agrees(lb, lo)
