@@ -124,3 +124,51 @@ def test_shared_prefix_pages_give_the_same_logits(eager):
     assert need.tolist() == [0]
     close(lb, lo)
     greedy_agrees(lb, lo)
+
+
+def test_decode_attention_properties_at_benchmark_size():
+    """The benchmark's dominant kernel at its benchmark shape (256 sequences x ~1000 keys, 16/8 heads): values that are
+    constant per kv head must come back unchanged (the softmax weights sum to one), and moving the pages of the cache
+    to other physical pages must not change a bit."""
+    from nanovllm import ops
+    b, hq, hkv, d = 256, 16, 8, 128
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(900, 1100, (b,), generator=g, dtype=torch.int32)
+    pages_per = 5
+    npages = b * pages_per
+    kc = (torch.randn(npages, 256, hkv, d, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    vc = torch.randn(npages, 256, hkv, d, generator=g).to(torch.bfloat16).cuda()
+    q = torch.randn(b, hq, d, generator=g).to(torch.bfloat16).cuda()
+    perm = torch.randperm(npages, generator=g).to(torch.int32)
+    bt = perm.view(b, pages_per).cuda()
+    scale = d ** -0.5
+    ctx = lens.cuda()
+    out = ops.attn_decode(q, kc, vc, ctx, bt, scale, num_splits=1)
+    # constant values per kv head
+    const = torch.arange(1, hkv + 1, dtype=torch.float32).view(1, 1, hkv, 1).expand(npages, 256, hkv, d).to(torch.bfloat16).cuda().contiguous()
+    same = ops.attn_decode(q, kc, const, ctx, bt, scale, num_splits=1).float()
+    want = torch.arange(1, hkv + 1, dtype=torch.float32).repeat_interleave(hq // hkv).view(1, hq, 1).cuda()
+    assert float((same - want).abs().max()) <= 2e-2
+    # relocate every page
+    perm2 = torch.randperm(npages, generator=g)
+    inv = torch.empty_like(perm2)
+    inv[perm2] = torch.arange(npages)
+    kc2, vc2 = kc[perm2.cuda()], vc[perm2.cuda()]               # new page j holds old page perm2[j]
+    bt2 = inv.to(torch.int32).cuda()[bt.long()]                 # old page p now lives at inv[p]
+    moved = ops.attn_decode(q, kc2, vc2, ctx, bt2, scale, num_splits=1)
+    assert torch.equal(out, moved)
+    # key-range splits agree with the unsplit result to rounding
+    split = ops.attn_decode(q, kc, vc, ctx, bt, scale, num_splits=4).float()
+    assert float((split - out.float()).abs().max()) <= 2e-2
+
+
+def test_lm_head_gemm_at_full_vocabulary_against_fp32():
+    """256 rows x 151936 outputs x 1024: every element against an fp32 matmul of the same bf16 operands."""
+    from nanovllm import ops
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(256, 1024, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(151936, 1024, generator=g) * 0.03).to(torch.bfloat16).cuda()
+    y = ops.linear(x, w).float()
+    ref = x.float() @ w.float().t()
+    err = (y - ref).abs()
+    assert bool((err <= 1e-2 + 8e-3 * ref.abs()).all()), f"max err {float(err.max()):.4g}"     # one bf16 rounding of the fp32 sum
