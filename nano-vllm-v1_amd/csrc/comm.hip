@@ -178,7 +178,11 @@ __global__ __launch_bounds__(kThreads) void allreduce_add_rmsnorm_kernel(CommDev
     comm_barrier(c, e0 + 1, staged);
     for (int64_t r = r_lo + wave; r < r_hi; r += kThreads / 64) {
         float v[MAXC][8];
-        float ss = 0.f;
+        // The sum of squares follows the stand-alone norm kernels bit for bit: rows of up to 1024 elements are one
+        // wave there too (one partial per lane); wider rows are four waves, thread t owning chunks t, t + 256, ..,
+        // reduced per wave and then (w0 + w1) + (w2 + w3) - here chunk lane + 64 i is that kernel's wave i mod 4.
+        const bool wide = dim > 1024;
+        float ssw[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int ch = lane + i * 64;
@@ -186,17 +190,24 @@ __global__ __launch_bounds__(kThreads) void allreduce_add_rmsnorm_kernel(CommDev
                 const bf16x8 s8 = sum_ranks(c, r * nchunk + ch);
                 const bf16x8 res = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + ch * 8);
                 bf16x8 nr;
+                float part = wide ? ssw[i & 3] : ssw[0];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float x = bf2f(s8[j]) + bf2f(res[j]);
                     nr[j] = f2bf(x);
                     v[i][j] = x;
-                    ss += x * x;
+                    part += x * x;
                 }
+                if (wide) ssw[i & 3] = part;
+                else ssw[0] = part;
                 *reinterpret_cast<bf16x8*>(residual + r * (int64_t)dim + ch * 8) = nr;
             }
         }
-        ss = wave_sum(ss);
+        float ss = wave_sum(ssw[0]);
+        if (wide) {
+            const float s1 = wave_sum(ssw[1]), s2 = wave_sum(ssw[2]), s3 = wave_sum(ssw[3]);
+            ss = (ss + s1) + (s2 + s3);
+        }
         const float inv = 1.0f / sqrtf(ss / (float)dim + eps);
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
