@@ -147,3 +147,46 @@ def test_preemption_is_lifo_and_blocks_admission():
     seqs = sched.schedule()
     # b needs a new page, none is free: b (the newest running) is pre-empted and nothing is admitted this step
     assert seqs == [a] and list(sched.waiting) == [b, c] and not b.block_table and b.num_cached_tokens == 0
+
+
+def test_cpu_plumbing_one_prompt_through_scheduler_and_oracle():
+    """The CPU-runnable configuration: one 16-token prompt, 16 new tokens, greedy, with the scheduler and page manager
+    in the loop and the CPU oracle as the runner.  The ids must be the ones a plain loop over the oracle produces,
+    whether the prompt is prefilled at once or in chunks of 5 tokens; the pages are the ones the scheduler handed out."""
+    from conftest import TINY
+    from oracle import ref_model as M
+    from oracle import ref_ops as R
+    shape = M.ModelShape(**TINY)
+    weights = M.random_weights(shape, seed=0, std=0.05)
+    g = torch.Generator().manual_seed(16)
+    prompt = torch.randint(0, 1024, (16,), generator=g).tolist()
+
+    # plain loop: whole prompt, then one token at a time
+    oracle = M.RefRunner(shape, weights, 2)
+    st = M.SeqState(list(prompt), 0, 16, [1])
+    logits, _ = oracle.run([st])
+    want = []
+    for _ in range(16):
+        tok = int(R.greedy(logits)[0])
+        want.append(tok)
+        st.num_cached_tokens += st.num_new_tokens
+        st.token_ids.append(tok)
+        st.num_new_tokens = 1
+        logits, _ = oracle.run([st])
+
+    for budget in (1024, 5):
+        cfg = dict(BASE, num_kvcache_blocks=2, max_num_batched_tokens=budget, chunked_prefill=True)
+        sched = Scheduler(SimpleNamespace(**cfg))
+        seq = Sequence(list(prompt), SamplingParams(temperature=1.0, max_tokens=16, ignore_eos=True))
+        sched.add(seq)
+        oracle = M.RefRunner(shape, weights, 2)
+        steps = 0
+        while not sched.is_finished():
+            seqs = sched.schedule()
+            states = [M.SeqState(list(s.token_ids), s.num_cached_tokens, s.num_new_tokens, list(s.block_table)) for s in seqs]
+            logits, need = oracle.run(states)
+            toks = R.greedy(logits).tolist() if need.numel() else []
+            sched.postprocess(seqs, toks, need.tolist())
+            steps += 1
+        assert seq.completion_token_ids == want, f"budget {budget}"
+        assert steps == (16 if budget == 1024 else 19)         # 1 (or 4) prefill steps + 15 decode steps
