@@ -336,7 +336,9 @@ class ModelRunner:
             new = np.diff(fb["cu_seqlens_q"])
             other = np.flatnonzero(new != 1)
             prefix = int(other[0]) if other.size else len(new)
-            if prefix >= 8:
+            # worth two more launches per layer from 8 sequences on, or for any number of them once their contexts are
+            # long (each would otherwise walk its whole context as a 64-row block of the var-len kernel)
+            if prefix >= 8 or (prefix >= 1 and int(fb["context_lens"][:prefix].max()) >= 1024):
                 arrays["cu_seqlens_q_tail"] = fb["cu_seqlens_q"][prefix:] - fb["cu_seqlens_q"][prefix]
                 arrays["cu_seqlens_k_tail"] = fb["cu_seqlens_k"][prefix:] - fb["cu_seqlens_k"][prefix]
             else:
