@@ -150,14 +150,16 @@ int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch, int64_t n
 
 /* ---- K3: paged decode attention, one query per sequence.
  * layers/attention.py:222-234 (flash_attn_with_kvcache).  q [B,Hq,D]; context_lens int32 [B]
- * (0 = padded row -> zero output); new K/V already stored.  num_splits > 1 splits every
- * sequence's keys over that many workgroups (fixed grid: safe under graph replay with
- * changing context_lens) and needs `workspace`. */
+ * (0 = padded row -> zero output); new K/V already stored.  num_splits > 1 offers every sequence that many key
+ * ranges, each handled by its own workgroup (fixed grid: safe under graph replay with changing context_lens), and
+ * needs `workspace`.  A sequence of ctx keys uses ranges of max(ceil(ctx / num_splits) rounded up to 64,
+ * min_range_keys) keys: min_range_keys (a multiple of 64; 0 = 64) keeps short sequences in one range, finished
+ * without partial results, while a long sequence in the same batch is spread over up to num_splits workgroups. */
 int32_t nvh_attn_decode(const void* q, int64_t q_token_stride,
                         const void* k_cache, const void* v_cache,
                         const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
                         int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                        float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                        float softmax_scale, void* out, int32_t num_splits, int32_t min_range_keys, void* workspace,
                         nvh_stream_t stream);
 /* Decode step fusion: `qkv` is the raw fused projection output [B, (Hq+2Hkv)*D] of the single new token of
  * every sequence.  One launch applies the per-head RMSNorm + RoPE to q and k (models/qwen3.py:191-195),
@@ -168,8 +170,30 @@ int32_t nvh_attn_decode_fused_qkv(const void* qkv, int64_t token_stride, const v
                                   const float* cos_sin, void* k_cache, void* v_cache,
                                   const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
                                   int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                                  float softmax_scale, void* out, int32_t num_splits, void* workspace,
-                                  nvh_stream_t stream);
+                                  float softmax_scale, void* out, int32_t num_splits, int32_t min_range_keys,
+                                  void* workspace, nvh_stream_t stream);
+/* The same two launches over an explicit work list instead of the uniform num_splits x batch grid (no counterpart in
+ * the reference, whose flash_attn_with_kvcache call splits keys internally): item i is key range item_range[i] of
+ * sequence item_seq[i] (-1 = unused slot); sequence b has seq_active[b] ranges of seq_chunk[b] keys (a multiple of
+ * 64), seq_active[b] <= max_ranges.  Every sequence needs an item for each of its ranges (range 0 also for padded
+ * rows, which write zeros); num_items >= batch.  A sequence with one range is finished by its workgroup, the
+ * others through `workspace` (nvh_attn_decode_workspace_bytes(batch, Hq, D, max_ranges)).  For batches of many
+ * short sequences and a few very long ones: neither a serial walk over the long ones nor a grid of idle workgroups. */
+int32_t nvh_attn_decode_items(const void* q, int64_t q_token_stride,
+                              const void* k_cache, const void* v_cache,
+                              const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                              int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                              float softmax_scale, void* out, const int32_t* item_seq, const int32_t* item_range,
+                              const int32_t* seq_active, const int32_t* seq_chunk, int64_t num_items, int32_t max_ranges,
+                              void* workspace, nvh_stream_t stream);
+int32_t nvh_attn_decode_fused_qkv_items(const void* qkv, int64_t token_stride, const void* q_norm_weight,
+                                        const void* k_norm_weight, float eps, const int64_t* positions,
+                                        const float* cos_sin, void* k_cache, void* v_cache,
+                                        const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                        int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                        float softmax_scale, void* out, const int32_t* item_seq, const int32_t* item_range,
+                                        const int32_t* seq_active, const int32_t* seq_chunk, int64_t num_items,
+                                        int32_t max_ranges, void* workspace, nvh_stream_t stream);
 int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t head_dim, int32_t num_splits);
 int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int64_t max_context);
 
@@ -274,6 +298,7 @@ typedef struct {
     int64_t table_stride;
     int32_t max_seqlen_q, max_seqlen_k;
     int32_t mode, decode_splits;       /* decode_splits >= 1 */
+    int32_t decode_min_range;          /* min_range_keys of the decode attention launches (0 = 64) */
     /* Mixed steps (mode PAGED) whose first `decode_prefix` sequences have exactly one new token each (the running
      * sequences of a serving step): their attention goes through the decode kernel (with `decode_splits` key
      * ranges), the remaining sequences through the var-len kernel with the two arrays below = cu_seqlens of
@@ -282,6 +307,10 @@ typedef struct {
      * sequence made that call half of the GPU time of a saturated serving run.  0 = no split. */
     int64_t decode_prefix;
     const int32_t *cu_seqlens_q_tail, *cu_seqlens_k_tail;
+    /* decode_items > 0: the decode attention launches (mode DECODE, or the decode_prefix of a mixed step) run over
+     * this work list (nvh_attn_decode_fused_qkv_items) with decode_splits as max_ranges. */
+    int64_t decode_items;
+    const int32_t *decode_item_seq, *decode_item_range, *decode_seq_active, *decode_seq_chunk;
 } nvh_step;
 
 int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_tokens, int64_t batch, int32_t decode_splits);

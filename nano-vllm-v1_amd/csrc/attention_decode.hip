@@ -7,11 +7,33 @@
 // and each loop trip consumes 64 consecutive tokens (always inside one 256-token page, so the
 // block-table entry is a single scalar load per trip).  Every row keeps its own online-softmax
 // state (max, sum, 8 output columns per lane); rows are merged once at the end (shuffles inside
-// the wave, LDS across waves).  With num_splits > 1 the per-range results go to a workspace as
-// (max, sum, unnormalised fp32 output) and attn_decode_combine_kernel finishes them.
+// the wave, LDS across waves).  Key ranges: the grid offers num_splits ranges per sequence, a sequence of ctx keys
+// uses ranges of max(ceil(ctx / num_splits) rounded up to 64, min_range) keys, i.e. only as many as its length
+// calls for (workgroups of unused ranges leave at once).  A sequence that fits ONE range is finished by its
+// workgroup; longer ones leave (max, sum, unnormalised fp32 output) per range in a workspace and the merge kernel
+// finishes them.  So one launch serves a batch of short sequences with a few very long ones without making the
+// short ones pay for partial results, and without the long ones walking their keys in a single workgroup.
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
+
+// Keys per range of a sequence of `ctx` keys when the launch offers `num_splits` ranges (see the file header).
+__device__ __forceinline__ int decode_range_keys(int ctx, int num_splits, int min_range) {
+    const int even = (((ctx + num_splits - 1) / num_splits) + 63) & ~63;
+    return even > min_range ? even : min_range;
+}
+
+// Explicit work list (instead of the uniform num_splits x batch grid): item i of gridDim.z is range item_range[i] of
+// sequence item_seq[i] (-1: unused slot, the workgroup leaves); sequence b has seq_active[b] ranges of seq_chunk[b]
+// keys.  The caller lists one item per sequence plus extra items for the ranges 1.. of its long sequences, so a
+// batch of hundreds of short sequences and a few very long ones costs neither a serial walk over the long ones
+// nor a grid of empty workgroups (measured: ~10 ns per empty workgroup, 32768 of them per layer for 16 uniform
+// ranges at batch 256).  Partial results use max_ranges as the slab stride.
+struct DecodeItems {
+    const int32_t *item_seq, *item_range, *seq_active, *seq_chunk;
+    int batch;
+    int max_ranges;
+};
 
 // FUSED: `q` is the raw fused qkv row of the step's single new token per sequence.  The kernel applies the
 // q/k epilogue itself (per-head RMSNorm + RoPE, qknorm_rope_head), uses the new token's K/V straight from
@@ -29,18 +51,35 @@ template <int G, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(
     const bf16* __restrict__ q, int64_t q_stride, bf16* __restrict__ kc, bf16* __restrict__ vc,
     const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ tables, int64_t table_stride, int hkv,
-    float scale_log2, bf16* __restrict__ out, float* __restrict__ ws_acc, float* __restrict__ ws_ml, FusedQkv fz) {
+    float scale_log2, bf16* __restrict__ out, float* __restrict__ ws_acc, float* __restrict__ ws_ml, int min_range, DecodeItems items, FusedQkv fz) {
     __shared__ float sm_acc[4][G][128];
     __shared__ float sm_ml[4][G][2];
 
-    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
-    const int num_splits = gridDim.x;
+    const int kvh = blockIdx.y;
     const int hq = hkv * G;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15;
     const int rowid = w * 4 + (lane >> 4);
 
-    const int ctx = ctx_lens[b];
-    const int chunk = (((ctx + num_splits - 1) / num_splits) + 63) & ~63;
+    int split, b, num_splits, ctx, chunk, active;
+    if (items.item_seq) {                                    // work list
+        b = items.item_seq[blockIdx.z];
+        if (b < 0 || b >= items.batch) return;               // block-uniform: unused slot
+        split = items.item_range[blockIdx.z];
+        num_splits = items.max_ranges;
+        ctx = ctx_lens[b];
+        chunk = max(items.seq_chunk[b], 64);                 // a malformed list may drop keys, never leave the buffers
+        active = min(items.seq_active[b], num_splits);
+        if (split < 0) return;
+    } else {                                                 // uniform grid
+        split = blockIdx.x;
+        b = blockIdx.z;
+        num_splits = gridDim.x;
+        ctx = ctx_lens[b];
+        chunk = decode_range_keys(ctx, num_splits, min_range);
+        active = ctx > 0 ? (ctx + chunk - 1) / chunk : 0;
+    }
+    if (split >= max(active, 1)) return;                     // block-uniform: this range holds no key of the sequence
+    const bool final_here = active <= 1;                     // the whole sequence (or a padded row) is this workgroup's
     const int start = split * chunk;
     const int end = min(ctx, start + chunk);
 
@@ -175,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
             A += sm_acc[ww][g][d] * sc;
         }
         const int h = kvh * G + g;
-        if (num_splits == 1) {
+        if (final_here) {
             out[((int64_t)b * hq + h) * 128 + d] = f2bf(L > 0.f ? A / L : 0.f);
         } else {
             const int64_t slab = ((int64_t)b * hq + h) * num_splits + split;
@@ -194,22 +233,32 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
 //  * wave-per-row (4 rows per workgroup, no LDS): many rows (prefill with key ranges, large decode batches);
 //  * workgroup-per-row (wave w owns accumulator w): few rows, where the chain of dependent loads of one wave
 //    would be the whole cost.  With `ctx_lens` it only visits the ranges the decode kernel gave keys to.
-__device__ __forceinline__ int active_ranges(const int32_t* ctx_lens, int64_t bh, int hq, int num_splits) {
+// Ranges of row bh that hold partial results.  Decode rows (ctx_lens given) follow decode_range_keys; a row whose
+// sequence fits one range was finished by the attention kernel itself and reports -1 (nothing to merge).
+__device__ __forceinline__ int active_ranges(const int32_t* ctx_lens, int64_t bh, int hq, int num_splits, int min_range,
+                                             const int32_t* seq_active) {
+    if (seq_active) {
+        const int a = min(seq_active[bh / hq], num_splits);
+        return a > 1 ? a : -1;
+    }
     if (!ctx_lens) return num_splits;
     const int ctx = ctx_lens[bh / hq];
-    if (ctx <= 0) return 0;
-    const int chunk = (((ctx + num_splits - 1) / num_splits) + 63) & ~63;     // as attn_decode_kernel
-    return (ctx + chunk - 1) / chunk;
+    if (ctx <= 0) return -1;
+    const int chunk = decode_range_keys(ctx, num_splits, min_range);
+    const int active = (ctx + chunk - 1) / chunk;
+    return active > 1 ? active : -1;
 }
 
 __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
                                                                   const float* __restrict__ ws_ml,
                                                                   bf16* __restrict__ out, int num_splits, int64_t rows,
-                                                                  const int32_t* __restrict__ ctx_lens, int hq) {
+                                                                  const int32_t* __restrict__ ctx_lens, int hq, int min_range,
+                                                                  const int32_t* __restrict__ seq_active) {
     const int lane = threadIdx.x & 63;
     const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (bh >= rows) return;
-    const int active = active_ranges(ctx_lens, bh, hq, num_splits);
+    const int active = active_ranges(ctx_lens, bh, hq, num_splits, min_range, seq_active);
+    if (active < 0) return;
     const f32x2* ml = reinterpret_cast<const f32x2*>(ws_ml) + bh * num_splits;
     float m_loc = -INFINITY;
     for (int s = lane; s < active; s += 64) {
@@ -253,11 +302,13 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
 __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const float* __restrict__ ws_acc,
                                                                       const float* __restrict__ ws_ml,
                                                                       bf16* __restrict__ out, int num_splits,
-                                                                      const int32_t* __restrict__ ctx_lens, int hq) {
+                                                                      const int32_t* __restrict__ ctx_lens, int hq, int min_range,
+                                                                  const int32_t* __restrict__ seq_active) {
     __shared__ f32x2 part[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t bh = blockIdx.x;
-    const int active = active_ranges(ctx_lens, bh, hq, num_splits);
+    const int active = active_ranges(ctx_lens, bh, hq, num_splits, min_range, seq_active);
+    if (active < 0) return;                                        // block-uniform
     const f32x2* ml = reinterpret_cast<const f32x2*>(ws_ml) + bh * num_splits;
     // every wave derives the row maximum and the weights itself (<= 256 ranges: 4 records per lane)
     f32x2 rec[4];
@@ -312,11 +363,12 @@ __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const floa
 }
 
 int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits,
-                                const int32_t* ctx_lens, int hq, hipStream_t st) {
+                                const int32_t* ctx_lens, int hq, int min_range, const int32_t* seq_active, hipStream_t st) {
     if (rows <= 2048 && num_splits <= 256)
-        attn_decode_combine_row_kernel<<<(unsigned)rows, 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, ctx_lens, hq);
+        attn_decode_combine_row_kernel<<<(unsigned)rows, 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, ctx_lens, hq, min_range, seq_active);
     else
-        attn_decode_combine_kernel<<<(unsigned)nvh_cdiv(rows, 4), 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, rows, ctx_lens, hq);
+        attn_decode_combine_kernel<<<(unsigned)nvh_cdiv(rows, 4), 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, rows, ctx_lens, hq, min_range,
+                                                                                seq_active);
     NVH_CHECK_LAUNCH("attn_combine");
     return NVH_OK;
 }
@@ -345,9 +397,11 @@ struct DecodeArgs {
     int64_t table_stride, batch, num_q_heads, num_kv_heads, head_dim;
     float softmax_scale;
     void* out;
-    int32_t num_splits;
+    int32_t num_splits, min_range;
     void* workspace;
     hipStream_t st;
+    DecodeItems items;              // item_seq == nullptr: uniform grid
+    int64_t num_items;
 };
 
 template <bool FUSED>
@@ -360,16 +414,24 @@ int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz)
     NVH_REQUIRE(a.num_splits >= 1 && a.num_splits <= 256 && (a.num_splits == 1 || a.workspace), NVH_EINVAL,
                 "%s: num_splits %d needs a workspace", name, a.num_splits);
     NVH_REQUIRE(a.batch <= 65535 && a.num_kv_heads <= 65535, NVH_EINVAL, "%s: batch/heads exceed grid limits", name);
+    NVH_REQUIRE(a.min_range >= 0 && a.min_range % 64 == 0, NVH_EINVAL, "%s: min_range_keys %d must be a multiple of 64 (0 = 64)", name, a.min_range);
+    const int min_range = a.min_range > 0 ? a.min_range : 64;
     if (a.batch == 0) return NVH_OK;
     const int g = (int)(a.num_q_heads / a.num_kv_heads);
     float* ws_acc = (float*)a.workspace;
     float* ws_ml = ws_acc ? ws_acc + a.batch * a.num_q_heads * a.num_splits * 128 : nullptr;
     dim3 grid((unsigned)a.num_splits, (unsigned)a.num_kv_heads, (unsigned)a.batch);
+    if (a.items.item_seq) {
+        NVH_REQUIRE(a.items.item_range && a.items.seq_active && a.items.seq_chunk && a.num_items >= a.batch && a.num_items <= 65535 &&
+                        a.items.max_ranges == a.num_splits,
+                    NVH_EINVAL, "%s: work list needs all four arrays, batch <= items <= 65535 and max_ranges == num_splits", name);
+        grid = dim3(1, (unsigned)a.num_kv_heads, (unsigned)a.num_items);
+    }
     const float sl2 = a.softmax_scale * LOG2E;
 #define LAUNCH_DEC(GG)                                                                                                  \
     attn_decode_kernel<GG, FUSED><<<grid, 256, 0, a.st>>>((const bf16*)a.q, a.q_token_stride, (bf16*)a.k_cache, (bf16*)a.v_cache, \
                                                           a.context_lens, a.block_tables, a.table_stride, (int)a.num_kv_heads, \
-                                                          sl2, (bf16*)a.out, ws_acc, ws_ml, fz)
+                                                          sl2, (bf16*)a.out, ws_acc, ws_ml, min_range, a.items, fz)
     switch (g) {
         case 1: LAUNCH_DEC(1); break;
         case 2: LAUNCH_DEC(2); break;
@@ -383,7 +445,8 @@ int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz)
 #undef LAUNCH_DEC
     NVH_CHECK_LAUNCH(name);
     if (a.num_splits > 1)
-        return nvh_launch_attn_combine(ws_acc, ws_ml, a.out, a.batch * a.num_q_heads, a.num_splits, a.context_lens, (int)a.num_q_heads, a.st);
+        return nvh_launch_attn_combine(ws_acc, ws_ml, a.out, a.batch * a.num_q_heads, a.num_splits, a.context_lens, (int)a.num_q_heads,
+                                       min_range, a.items.seq_active, a.st);
     return NVH_OK;
 }
 }  // namespace
@@ -391,12 +454,25 @@ int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz)
 extern "C" int32_t nvh_attn_decode(const void* q, int64_t q_token_stride, const void* k_cache, const void* v_cache,
                                    const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
                                    int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                                   float softmax_scale, void* out, int32_t num_splits, void* workspace,
+                                   float softmax_scale, void* out, int32_t num_splits, int32_t min_range_keys, void* workspace,
                                    nvh_stream_t stream) {
     DecodeArgs a{q, q_token_stride, const_cast<void*>(k_cache), const_cast<void*>(v_cache), context_lens, block_tables,
-                 table_stride, batch, num_q_heads, num_kv_heads, head_dim, softmax_scale, out, num_splits, workspace,
-                 (hipStream_t)stream};
+                 table_stride, batch, num_q_heads, num_kv_heads, head_dim, softmax_scale, out, num_splits, min_range_keys, workspace,
+                 (hipStream_t)stream, DecodeItems{}, 0};
     return launch_decode<false>("nvh_attn_decode", a, FusedQkv{});
+}
+
+extern "C" int32_t nvh_attn_decode_items(const void* q, int64_t q_token_stride, const void* k_cache, const void* v_cache,
+                                         const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                         int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                         float softmax_scale, void* out, const int32_t* item_seq, const int32_t* item_range,
+                                         const int32_t* seq_active, const int32_t* seq_chunk, int64_t num_items, int32_t max_ranges,
+                                         void* workspace, nvh_stream_t stream) {
+    NVH_REQUIRE(item_seq, NVH_EINVAL, "nvh_attn_decode_items: null work list");
+    DecodeArgs a{q, q_token_stride, const_cast<void*>(k_cache), const_cast<void*>(v_cache), context_lens, block_tables,
+                 table_stride, batch, num_q_heads, num_kv_heads, head_dim, softmax_scale, out, max_ranges, 0, workspace,
+                 (hipStream_t)stream, DecodeItems{item_seq, item_range, seq_active, seq_chunk, (int)batch, max_ranges}, num_items};
+    return launch_decode<false>("nvh_attn_decode_items", a, FusedQkv{});
 }
 
 extern "C" int32_t nvh_attn_decode_fused_qkv(const void* qkv, int64_t token_stride, const void* q_norm_weight,
@@ -404,13 +480,31 @@ extern "C" int32_t nvh_attn_decode_fused_qkv(const void* qkv, int64_t token_stri
                                              const float* cos_sin, void* k_cache, void* v_cache,
                                              const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
                                              int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                                             float softmax_scale, void* out, int32_t num_splits, void* workspace,
-                                             nvh_stream_t stream) {
+                                             float softmax_scale, void* out, int32_t num_splits, int32_t min_range_keys,
+                                             void* workspace, nvh_stream_t stream) {
     NVH_REQUIRE(q_norm_weight && k_norm_weight && positions && cos_sin, NVH_EINVAL, "nvh_attn_decode_fused_qkv: null pointer");
     NVH_REQUIRE(nvh_aligned16(q_norm_weight) && nvh_aligned16(k_norm_weight) && nvh_aligned16(cos_sin), NVH_EINVAL,
                 "nvh_attn_decode_fused_qkv: 16-byte alignment required");
     DecodeArgs a{qkv, token_stride, k_cache, v_cache, context_lens, block_tables, table_stride, batch, num_q_heads,
-                 num_kv_heads, head_dim, softmax_scale, out, num_splits, workspace, (hipStream_t)stream};
+                 num_kv_heads, head_dim, softmax_scale, out, num_splits, min_range_keys, workspace, (hipStream_t)stream, DecodeItems{}, 0};
     return launch_decode<true>("nvh_attn_decode_fused_qkv", a,
+                               FusedQkv{(const bf16*)q_norm_weight, (const bf16*)k_norm_weight, positions, cos_sin, eps});
+}
+
+extern "C" int32_t nvh_attn_decode_fused_qkv_items(const void* qkv, int64_t token_stride, const void* q_norm_weight,
+                                                   const void* k_norm_weight, float eps, const int64_t* positions,
+                                                   const float* cos_sin, void* k_cache, void* v_cache,
+                                                   const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                                   int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                                   float softmax_scale, void* out, const int32_t* item_seq,
+                                                   const int32_t* item_range, const int32_t* seq_active, const int32_t* seq_chunk,
+                                                   int64_t num_items, int32_t max_ranges, void* workspace, nvh_stream_t stream) {
+    NVH_REQUIRE(q_norm_weight && k_norm_weight && positions && cos_sin && item_seq, NVH_EINVAL, "nvh_attn_decode_fused_qkv_items: null pointer");
+    NVH_REQUIRE(nvh_aligned16(q_norm_weight) && nvh_aligned16(k_norm_weight) && nvh_aligned16(cos_sin), NVH_EINVAL,
+                "nvh_attn_decode_fused_qkv_items: 16-byte alignment required");
+    DecodeArgs a{qkv, token_stride, k_cache, v_cache, context_lens, block_tables, table_stride, batch, num_q_heads,
+                 num_kv_heads, head_dim, softmax_scale, out, max_ranges, 0, workspace, (hipStream_t)stream,
+                 DecodeItems{item_seq, item_range, seq_active, seq_chunk, (int)batch, max_ranges}, num_items};
+    return launch_decode<true>("nvh_attn_decode_fused_qkv_items", a,
                                FusedQkv{(const bf16*)q_norm_weight, (const bf16*)k_norm_weight, positions, cos_sin, eps});
 }

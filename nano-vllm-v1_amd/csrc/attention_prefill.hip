@@ -446,7 +446,7 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
 #undef LAUNCH_VL
     NVH_CHECK_LAUNCH("attn_varlen");
     if (num_splits > 1) {
-        return nvh_launch_attn_combine(ws_acc, ws_ml, out, total_q * num_q_heads, num_splits, nullptr, 1, st);   // same records as decode
+        return nvh_launch_attn_combine(ws_acc, ws_ml, out, total_q * num_q_heads, num_splits, nullptr, 1, 64, nullptr, st);   // same records as decode
     }
     return NVH_OK;
 }

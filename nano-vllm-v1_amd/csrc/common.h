@@ -40,7 +40,7 @@ void nvh_set_error(const char* fmt, ...);
 
 // Merge per-range attention partials ([row][split][128] fp32 + [row][split][2] (max, sum)) into bf16 rows.
 int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits,
-                                const int32_t* ctx_lens, int hq, hipStream_t st);
+                                const int32_t* ctx_lens, int hq, int min_range, const int32_t* seq_active, hipStream_t st);
 
 static inline bool nvh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int64_t nvh_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -61,6 +61,19 @@ extern "C" int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64
     return carve(model, num_tokens, batch, decode_splits < 1 ? 1 : decode_splits, kMaxVarlenSplits, nullptr).total;
 }
 
+// The fused decode attention of layer l over the first `rows` sequences of the step: uniform grid or work list.
+static int32_t decode_attention(const nvh_qwen3_model* md, const nvh_step* st, int l, const bf16* qkv, int64_t qkv_n, void* kc, void* vc,
+                                int64_t rows, float scale, bf16* attn, int32_t dsplits, void* ws, nvh_stream_t stream) {
+    if (st->decode_items > 0)
+        return nvh_attn_decode_fused_qkv_items(qkv, qkv_n, md->q_norm[l], md->k_norm[l], md->eps, st->positions, md->cos_sin, kc, vc,
+                                               st->context_lens, st->block_tables, st->table_stride, rows, md->num_q_heads,
+                                               md->num_kv_heads, md->head_dim, scale, attn, st->decode_item_seq, st->decode_item_range,
+                                               st->decode_seq_active, st->decode_seq_chunk, st->decode_items, dsplits, ws, stream);
+    return nvh_attn_decode_fused_qkv(qkv, qkv_n, md->q_norm[l], md->k_norm[l], md->eps, st->positions, md->cos_sin, kc, vc,
+                                     st->context_lens, st->block_tables, st->table_stride, rows, md->num_q_heads, md->num_kv_heads,
+                                     md->head_dim, scale, attn, dsplits, st->decode_min_range, ws, stream);
+}
+
 #define FWD(call)                 \
     do {                          \
         int32_t rc__ = (call);    \
@@ -137,9 +150,7 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
         static const bool fuse_decode = getenv("NVH_NO_FUSED_DECODE") == nullptr;   // A/B switch for measurements
         if (st->mode == NVH_MODE_DECODE && store && fuse_decode) {
             // one launch: q/k norm + RoPE + KV store of the new token + attention
-            FWD(nvh_attn_decode_fused_qkv(w.qkv, qkv_n, md->q_norm[l], md->k_norm[l], md->eps, st->positions, md->cos_sin, kc, vc,
-                                          st->context_lens, st->block_tables, st->table_stride, b, hq, hkv, d, scale, w.attn,
-                                          dsplits, w.decode_ws, stream));
+            FWD(decode_attention(md, st, l, w.qkv, qkv_n, kc, vc, b, scale, w.attn, dsplits, w.decode_ws, stream));
         } else {
             if (t > prefix)
                 FWD(nvh_qknorm_rope_store(w.qkv + prefix * qkv_n, qkv_n, hq, hkv, md->q_norm[l], md->k_norm[l], md->eps,
@@ -147,12 +158,10 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
                                           store ? vc : nullptr, store ? st->slot_mapping + prefix : nullptr, t - prefix, stream));
             if (st->mode == NVH_MODE_DECODE) {
                 FWD(nvh_attn_decode(w.qkv, qkv_n, kc, vc, st->context_lens, st->block_tables, st->table_stride, b, hq, hkv,
-                                    d, scale, w.attn, dsplits, w.decode_ws, stream));
+                                    d, scale, w.attn, dsplits, st->decode_min_range, w.decode_ws, stream));
             } else if (prefix > 0) {
                 // (the qk-norm / rope / store launch above covered only the tokens past the one-token sequences)
-                FWD(nvh_attn_decode_fused_qkv(w.qkv, qkv_n, md->q_norm[l], md->k_norm[l], md->eps, st->positions, md->cos_sin, kc, vc,
-                                              st->context_lens, st->block_tables, st->table_stride, prefix, hq, hkv, d, scale, w.attn,
-                                              dsplits, w.decode_ws, stream));
+                FWD(decode_attention(md, st, l, w.qkv, qkv_n, kc, vc, prefix, scale, w.attn, dsplits, w.decode_ws, stream));
                 if (b > prefix)
                     FWD(nvh_attn_varlen(w.qkv + prefix * qkv_n, qkv_n, kc, vc, kvsz, st->cu_seqlens_q_tail, st->cu_seqlens_k_tail,
                                         st->block_tables + prefix * st->table_stride, st->table_stride, b - prefix, st->max_seqlen_q,

@@ -36,7 +36,7 @@ SIGNATURES = {
     "nvh_attn_varlen": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
     "nvh_attn_varlen_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_varlen_suggest_splits": (i32, [i64, i64, i64, i64, i64]),
-    "nvh_attn_decode": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
+    "nvh_attn_decode": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, i32, vp, vp]),
     "nvh_comm_handle_bytes": (i32, []),
     "nvh_comm_create": (i32, [i32, i32, i64, vp]),
     "nvh_comm_get_handle": (i32, [vp, vp]),
@@ -48,7 +48,10 @@ SIGNATURES = {
     "nvh_gather_cols_bf16": (i32, [vp, vp, vp, i64, i64, i32, vp]),
     "nvh_comm_error": (i32, [vp]),
     "nvh_comm_destroy": (i32, [vp]),
-    "nvh_attn_decode_fused_qkv": (i32, [vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
+    "nvh_attn_decode_items": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, vp, vp, vp, vp, i64, i32, vp, vp]),
+    "nvh_attn_decode_fused_qkv_items": (i32, [vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp,
+                                              vp, vp, vp, vp, i64, i32, vp, vp]),
+    "nvh_attn_decode_fused_qkv": (i32, [vp, i64, vp, vp, f32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, i32, vp, vp]),
     "nvh_attn_decode_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_decode_suggest_splits": (i32, [i64, i64, i64]),
     "nvh_sample_workspace_bytes": (i64, [i64, i64]),

@@ -316,7 +316,7 @@ class ModelRunner:
                 module.k_cache = self.kv_cache[0, layer_id]
                 module.v_cache = self.kv_cache[1, layer_id]
                 module.max_context = cfg.max_model_len
-                module.split_fn = self.decode_splits
+                module.split_fn = self.module_decode_plan
                 layer_id += 1
 
     # -------------------------------------------------------------- per-step input
@@ -344,7 +344,16 @@ class ModelRunner:
             else:
                 prefix = 0
         fb["decode_prefix"] = prefix
+        # Work list of the decode attention when long and short contexts share the launch (see decode_plan).
+        rows = prefix if prefix else (len(seqs) if fb["block_tables"] is not None and fb["max_seqlen_q"] == 1 else 0)
+        plan = None
+        if self.native is not None and rows:
+            lens = fb["context_lens"][:rows]
+            if self.decode_plan(rows, int(lens.max()))[1]:
+                plan = ops.plan_decode_items(lens, max_ranges=self.MAX_RANGES)
+                arrays.update({k: plan[k] for k in ("item_seq", "item_range", "seq_active", "seq_chunk")})
         d = self.staging.upload(arrays)
+        fb["items"] = None if plan is None else {k: d[k] for k in ("item_seq", "item_range", "seq_active", "seq_chunk")}
         fb["tails"] = (d.get("cu_seqlens_q_tail"), d.get("cu_seqlens_k_tail"))
         set_context(d["cu_seqlens_q"], d["cu_seqlens_k"], fb["max_seqlen_q"], fb["max_seqlen_k"], d["slot_mapping"],
                     d["context_lens"], d.get("block_tables"), d["need"])
@@ -365,19 +374,21 @@ class ModelRunner:
             mode, splits = MODE_PACKED, 1
         elif fb["max_seqlen_q"] == 1:
             mode = MODE_DECODE
-            splits = self.decode_splits(bs)
+            splits = self.decode_plan(bs, fb["max_seqlen_k"])[0]
         else:
             mode, splits = MODE_PAGED, 1
         prefix = fb.get("decode_prefix", 0) if mode == MODE_PAGED else 0
         tails = fb.get("tails", (None, None))
         if prefix:
-            hkv = self.model.model.layers[0].self_attn.num_kv_heads
-            splits = ops.suggest_decode_splits(prefix, hkv, int(fb["context_lens"][:prefix].max()))
+            splits = self.decode_plan(prefix, int(fb["context_lens"][:prefix].max()))[0]
+        items = fb.get("items")
+        assert items is None or splits == self.MAX_RANGES
         return self.native.forward(input_ids, positions, mode=mode, batch=bs, cu_seqlens_q=ctx.cu_seqlens_q,
                                    cu_seqlens_k=ctx.cu_seqlens_k, max_seqlen_q=fb["max_seqlen_q"],
                                    max_seqlen_k=fb["max_seqlen_k"], slot_mapping=ctx.slot_mapping,
                                    context_lens=ctx.context_lens, block_tables=ctx.block_tables, decode_splits=splits,
-                                   decode_prefix=prefix, cu_seqlens_q_tail=tails[0], cu_seqlens_k_tail=tails[1])
+                                   decode_prefix=prefix, cu_seqlens_q_tail=tails[0], cu_seqlens_k_tail=tails[1],
+                                   decode_items=items)
 
     def decode_buckets(self) -> list[int]:
         max_bs = min(self.config.max_num_seqs, 512)
@@ -391,6 +402,32 @@ class ModelRunner:
         hkv = self.model.model.layers[0].self_attn.num_kv_heads
         return ops.suggest_decode_splits(bucket, hkv, self.config.max_model_len)
 
+    LONG_CONTEXT = 2048          # a batch whose longest context exceeds this takes the long-context decode plan
+    MAX_RANGES = 32              # key ranges a sequence can be cut into under that plan
+    ITEM_SLACK = 64              # work-list slots a captured graph holds beyond one per sequence
+
+    def decode_plan(self, bs: int, max_context: int) -> tuple[int, bool]:
+        """(key ranges per sequence, work list?) of the decode attention for a batch of `bs` whose longest context is
+        `max_context`.  Small batches already get many ranges each (to fill the chip) and need nothing else.  A large
+        batch gets few or one - right as long as every context is short; with a long context among them that
+        sequence would walk its keys in ONE workgroup per kv head and hold the whole step (256 sequences at 128 keys
+        and one at 8192: 6.2 ms instead of 2.5), while offering every sequence many ranges launches tens of
+        thousands of idle workgroups per layer.  Such a batch takes a work list (ops.plan_decode_items): the short
+        sequences stay in one range, each long one is cut into up to MAX_RANGES."""
+        short = self.decode_splits(bs)
+        if max_context <= self.LONG_CONTEXT or short >= 16:
+            return short, False
+        return self.MAX_RANGES, True
+
+    def module_decode_plan(self, bs: int, max_context: int) -> tuple[int, int]:
+        """(key ranges, minimum keys per range) for the operator-module path, which has no work list: up to 64
+        sequences with a long context among them are offered 16 ranges of at least 512 keys (short ones still use
+        one); larger batches keep the uniform split, where that many idle workgroups would cost more than they save."""
+        short = self.decode_splits(bs)
+        if max_context <= self.LONG_CONTEXT or short >= 16 or bs > 64:
+            return short, 0
+        return 16, 512
+
     def _graph_for(self, fb):
         """The captured graph that fits this step, or None (eager)."""
         bs = len(fb["context_lens"])
@@ -398,7 +435,13 @@ class ModelRunner:
                 or fb["input_ids"].size != bs or bs > self.graph_bs[-1]
                 or fb["block_tables"].shape[1] > self.graph_width):
             return None
-        return self.graphs[next(x for x in self.graph_bs if x >= bs)]
+        graph = self.graphs[next(x for x in self.graph_bs if x >= bs)]
+        if self.native is None:
+            if self.module_decode_plan(bs, fb["max_seqlen_k"]) != (graph.splits, 0):
+                return None                     # the graph was captured with the uniform split: eager
+        elif self.decode_plan(bs, fb["max_seqlen_k"])[1] and graph.graph_long is None:
+            return None
+        return graph
 
     @torch.inference_mode()
     def forward_logits(self, seqs):
@@ -461,8 +504,10 @@ class _DecodeGraph:
     def __init__(self, runner: ModelRunner, bs: int, width: int, pool):
         self.bs, self.width = bs, width
         dev = runner.device
+        self.items_cap = bs + runner.ITEM_SLACK
         sizes = dict(input_ids=bs * 8, positions=bs * 8, slot_mapping=bs * 4, context_lens=bs * 4,
-                     block_tables=bs * width * 4, temperatures=bs * 4)
+                     block_tables=bs * width * 4, temperatures=bs * 4, item_seq=self.items_cap * 4,
+                     item_range=self.items_cap * 4, seq_active=bs * 4, seq_chunk=bs * 4)
         self.offs, n = {}, 0
         for name, nbytes in sizes.items():
             self.offs[name] = (n, nbytes)
@@ -474,17 +519,22 @@ class _DecodeGraph:
         self.h = {k: v.numpy() for k, v in hv.items()}
         self.d = dv
         self.h["slot_mapping"][:] = -1
+        self._plan_items()
         self.dev.copy_(self.host)
         set_context(slot_mapping=dv["slot_mapping"], context_lens=dv["context_lens"], block_tables=dv["block_tables"])
+        self.splits = runner.decode_splits(bs)                        # batches without a long context
+        has_long = runner.native is not None and runner.decode_plan(bs, 1 << 30)[1]
+        self.graph_long = self.out_long = None
         if runner.native is not None:
-            splits = runner.decode_splits(bs)
-
-            def fwd():
+            items = {k: dv[k] for k in ("item_seq", "item_range", "seq_active", "seq_chunk")}
+            def fwd(long=False):
                 return runner.native.forward(dv["input_ids"], dv["positions"], mode=MODE_DECODE, batch=bs,
                                              slot_mapping=dv["slot_mapping"], context_lens=dv["context_lens"],
-                                             block_tables=dv["block_tables"], decode_splits=splits)
+                                             block_tables=dv["block_tables"],
+                                             decode_splits=runner.MAX_RANGES if long else self.splits,
+                                             decode_items=items if long else None)
         else:
-            def fwd():
+            def fwd(long=False):
                 return runner.model(dv["input_ids"], dv["positions"])
         fwd()                                                         # warm-up (allocator, lazy state)
         torch.cuda.synchronize()
@@ -492,7 +542,21 @@ class _DecodeGraph:
         with torch.cuda.graph(self.graph, pool):
             self.out = fwd()
         self.pool = self.graph.pool()
+        if has_long:                                                  # second capture: attention over the work list
+            fwd(True)
+            torch.cuda.synchronize()
+            self.graph_long = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_long, self.pool):
+                self.out_long = fwd(True)
+        self.runner = runner
         reset_context()
+
+    def _plan_items(self):
+        """Work list for the context lengths now in the host buffer (padding rows: one empty range each)."""
+        h = self.h
+        plan = ops.plan_decode_items(h["context_lens"], max_ranges=ModelRunner.MAX_RANGES, capacity=self.items_cap)
+        for k in ("item_seq", "item_range", "seq_active", "seq_chunk"):
+            h[k][:] = plan[k]
 
     def _views(self, buf):
         bs, w = self.bs, self.width
@@ -501,7 +565,9 @@ class _DecodeGraph:
             return buf[o:o + nb].view(dtype).view(*shape)
         return dict(input_ids=v("input_ids", torch.int64, bs), positions=v("positions", torch.int64, bs),
                     slot_mapping=v("slot_mapping", torch.int32, bs), context_lens=v("context_lens", torch.int32, bs),
-                    block_tables=v("block_tables", torch.int32, bs, w), temperatures=v("temperatures", torch.float32, bs))
+                    block_tables=v("block_tables", torch.int32, bs, w), temperatures=v("temperatures", torch.float32, bs),
+                    item_seq=v("item_seq", torch.int32, self.items_cap), item_range=v("item_range", torch.int32, self.items_cap),
+                    seq_active=v("seq_active", torch.int32, bs), seq_chunk=v("seq_chunk", torch.int32, bs))
 
     def replay(self, fb, seqs, want_temps: bool):
         n = len(seqs)
@@ -518,7 +584,14 @@ class _DecodeGraph:
         h["block_tables"][:n, :tb.shape[1]] = tb
         if want_temps:
             h["temperatures"][:n] = np.fromiter((s.temperature for s in seqs), dtype=np.float32, count=n)
+        long = self.graph_long is not None and self.runner.decode_plan(n, fb["max_seqlen_k"])[1]
+        if long:
+            self._plan_items()
         self.dev.copy_(self.host, non_blocking=True)
         self.event.record()
+        temps = self.d["temperatures"][:n] if want_temps else None
+        if long:
+            self.graph_long.replay()
+            return self.out_long, temps
         self.graph.replay()
-        return self.out, (self.d["temperatures"][:n] if want_temps else None)
+        return self.out, temps

@@ -37,19 +37,21 @@ class Attention(nn.Module):
         self.k_cache = self.v_cache = torch.tensor([])
         self.decode_splits = 0          # 0 = heuristic per call
         self.max_context = None
-        self.split_fn = None            # batch -> key-range count; the runner installs one policy for eager and graph steps
+        self.split_fn = None            # (batch, longest context) -> (key ranges, minimum keys per range); the runner
+                                        # installs one policy for eager and graph steps
 
     def attend(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         """Attention proper, with the new K/V already in the cache (or no cache bound)."""
         ctx = get_context()
-        splits = self.split_fn(q.shape[0]) if self.split_fn is not None else self.decode_splits
+        splits, min_range = (self.split_fn(q.shape[0], ctx.max_seqlen_k or 0) if self.split_fn is not None
+                             else (self.decode_splits, 0))
         if ctx.cu_seqlens_q is None:
             return ops.attn_decode(q, self.k_cache, self.v_cache, ctx.context_lens, ctx.block_tables, self.scale,
-                                   splits, self.max_context)
+                                   splits, self.max_context, min_range)
         if ctx.block_tables is not None:
             if ctx.max_seqlen_q == 1 and ctx.context_lens is not None:
                 return ops.attn_decode(q, self.k_cache, self.v_cache, ctx.context_lens, ctx.block_tables, self.scale,
-                                       splits, ctx.max_seqlen_k)
+                                       splits, ctx.max_seqlen_k, min_range)
             return ops.attn_varlen(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q, ctx.cu_seqlens_k,
                                    ctx.max_seqlen_q, self.scale, ctx.block_tables, ctx.max_seqlen_k or None)
         return ops.attn_varlen(q, k, v, ctx.cu_seqlens_q, ctx.cu_seqlens_k, ctx.max_seqlen_q, self.scale,

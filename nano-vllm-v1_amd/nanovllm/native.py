@@ -30,7 +30,9 @@ class StepDesc(C.Structure):
     _fields_ = [("num_tokens", i64), ("batch", i64), ("input_ids", vp), ("positions", vp), ("cu_seqlens_q", vp),
                 ("cu_seqlens_k", vp), ("slot_mapping", vp), ("context_lens", vp), ("block_tables", vp),
                 ("table_stride", i64), ("max_seqlen_q", i32), ("max_seqlen_k", i32), ("mode", i32), ("decode_splits", i32),
-                ("decode_prefix", i64), ("cu_seqlens_q_tail", vp), ("cu_seqlens_k_tail", vp)]
+                ("decode_min_range", i32), ("decode_prefix", i64), ("cu_seqlens_q_tail", vp), ("cu_seqlens_k_tail", vp),
+                ("decode_items", i64), ("decode_item_seq", vp), ("decode_item_range", vp), ("decode_seq_active", vp),
+                ("decode_seq_chunk", vp)]
 
 
 def _ptr(t):
@@ -96,7 +98,8 @@ class NativeQwen3:
 
     def forward(self, input_ids, positions, *, mode, batch, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0,
                 max_seqlen_k=0, slot_mapping=None, context_lens=None, block_tables=None, decode_splits=1,
-                decode_prefix=0, cu_seqlens_q_tail=None, cu_seqlens_k_tail=None):
+                decode_prefix=0, cu_seqlens_q_tail=None, cu_seqlens_k_tail=None, decode_min_range=0,
+                decode_items=None):
         t = input_ids.numel()
         st = StepDesc()
         st.num_tokens, st.batch = t, batch
@@ -106,6 +109,11 @@ class NativeQwen3:
         st.block_tables = _ptr(block_tables)
         st.table_stride = block_tables.stride(0) if block_tables is not None else 0
         st.max_seqlen_q, st.max_seqlen_k, st.mode, st.decode_splits = max_seqlen_q, max_seqlen_k, mode, max(1, decode_splits)
+        st.decode_min_range = decode_min_range
+        if decode_items is not None:               # work list of the decode attention: dict of int32 device tensors
+            st.decode_items = decode_items["item_seq"].numel()
+            st.decode_item_seq, st.decode_item_range = decode_items["item_seq"].data_ptr(), decode_items["item_range"].data_ptr()
+            st.decode_seq_active, st.decode_seq_chunk = decode_items["seq_active"].data_ptr(), decode_items["seq_chunk"].data_ptr()
         if decode_prefix:
             st.decode_prefix = decode_prefix
             st.cu_seqlens_q_tail, st.cu_seqlens_k_tail = _ptr(cu_seqlens_q_tail), _ptr(cu_seqlens_k_tail)

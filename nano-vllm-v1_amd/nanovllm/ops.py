@@ -237,15 +237,74 @@ def suggest_decode_splits(batch: int, num_kv_heads: int, max_context: int) -> in
     return _hip.lib().nvh_attn_decode_suggest_splits(batch, num_kv_heads, max_context)
 
 
+def plan_decode_items(context_lens, max_ranges: int = 32, range_keys: int = 0, capacity: int = 0) -> dict:
+    """Work list of the decode attention for a batch of uneven context lengths (host side, numpy): one item per
+    key range, where only sequences that hold at least two ranges' worth of keys are cut into ranges.  A range
+    is `range_keys` keys (0: total keys / 512, kept within 512..2048) and a sequence has at most `max_ranges`;
+    `capacity` > 0 fixes the list length (unused slots -1) and widens the ranges until the list fits it.
+    Returns int32 arrays item_seq, item_range [items], seq_active, seq_chunk [B] and max_ranges."""
+    import numpy as np
+    ctx = np.maximum(np.asarray(context_lens, dtype=np.int64), 0)
+    b = ctx.size
+    assert capacity <= 0 or capacity >= b
+    if range_keys <= 0:
+        range_keys = min(2048, max(512, (-(-int(ctx.sum()) // 512) + 63) // 64 * 64))
+    while True:
+        active = np.clip(ctx // range_keys, 1, max_ranges)
+        if capacity <= 0 or int(active.sum()) <= capacity:
+            break
+        range_keys *= 2
+    chunk = np.maximum(64, (-(-ctx // active) + 63) // 64 * 64)
+    active = np.maximum(1, -(-ctx // chunk))              # rounding the range up to 64 keys can empty the last one
+    n = capacity if capacity > 0 else int(active.sum())
+    # longest items first: workgroups are dispatched in list order, and a long range started last would run on alone
+    order = np.argsort(-chunk * (active > 1), kind="stable")
+    reps = active[order]
+    total = int(reps.sum())
+    item_seq, item_range = np.full(n, -1, np.int32), np.zeros(n, np.int32)
+    item_seq[:total] = np.repeat(order, reps)
+    item_range[:total] = np.arange(total) - np.repeat(np.cumsum(reps) - reps, reps)
+    return {"item_seq": item_seq, "item_range": item_range, "seq_active": active.astype(np.int32),
+            "seq_chunk": chunk.astype(np.int32), "max_ranges": max_ranges}
+
+
+def upload_decode_items(plan: dict, device, out: torch.Tensor | None = None) -> dict:
+    """The plan's four arrays in one int32 device tensor (one copy); `out` reuses a buffer of the right length."""
+    import numpy as np
+    packed = np.concatenate([plan["item_seq"], plan["item_range"], plan["seq_active"], plan["seq_chunk"]])
+    host = torch.from_numpy(packed)
+    if out is None:
+        out = host.to(device, non_blocking=False)
+    else:
+        assert out.numel() == packed.size and out.dtype == torch.int32
+        out.copy_(host, non_blocking=False)
+    n, b = plan["item_seq"].size, plan["seq_active"].size
+    return {"item_seq": out[:n], "item_range": out[n:2 * n], "seq_active": out[2 * n:2 * n + b],
+            "seq_chunk": out[2 * n + b:2 * n + 2 * b], "max_ranges": plan["max_ranges"]}
+
+
+def _items_args(items, batch):
+    assert all(items[k].dtype == torch.int32 and items[k].is_cuda and items[k].is_contiguous()
+               for k in ("item_seq", "item_range", "seq_active", "seq_chunk"))
+    assert items["item_seq"].numel() == items["item_range"].numel() >= batch
+    assert items["seq_active"].numel() == items["seq_chunk"].numel() == batch
+    return (items["item_seq"].data_ptr(), items["item_range"].data_ptr(), items["seq_active"].data_ptr(),
+            items["seq_chunk"].data_ptr(), items["item_seq"].numel(), items["max_ranges"])
+
+
 def attn_decode(q, k_cache, v_cache, context_lens, block_tables, scale: float, num_splits: int = 0,
-                max_context: int | None = None) -> torch.Tensor:
-    """q [B,Hq,128] (token stride free); caches [P,256,Hkv,128]; one query per sequence."""
+                max_context: int | None = None, min_range: int = 0, items: dict | None = None) -> torch.Tensor:
+    """q [B,Hq,128] (token stride free); caches [P,256,Hkv,128]; one query per sequence.  `num_splits` key ranges
+    are offered to every sequence, of at least `min_range` keys each (0 = 64); or `items`, an uploaded
+    plan_decode_items work list, names the ranges one by one."""
     _gpu_bf16(q, k_cache, v_cache)
     b, hq, d = q.shape
     hkv = k_cache.shape[2]
     assert q.stride(2) == 1 and q.stride(1) == d and k_cache.is_contiguous() and v_cache.is_contiguous()
     assert context_lens.dtype == torch.int32 and block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
-    if num_splits <= 0:
+    if items is not None:
+        num_splits = items["max_ranges"]
+    elif num_splits <= 0:
         mc = max_context if max_context is not None else block_tables.shape[1] * KV_PAGE
         num_splits = suggest_decode_splits(b, hkv, mc)
     out = torch.empty(b, hq, d, dtype=BF16, device=q.device)
@@ -254,21 +313,28 @@ def attn_decode(q, k_cache, v_cache, context_lens, block_tables, scale: float, n
         nbytes = _hip.lib().nvh_attn_decode_workspace_bytes(b, hq, d, num_splits)
         ws_t = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
         ws = ws_t.data_ptr()
+    if items is not None:
+        _hip.call("nvh_attn_decode_items", q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
+                  context_lens.data_ptr(), block_tables.data_ptr(), block_tables.stride(0), b, hq, hkv, d, float(scale),
+                  out.data_ptr(), *_items_args(items, b), ws, _stream())
+        return out
     _hip.call("nvh_attn_decode", q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(),
               context_lens.data_ptr(), block_tables.data_ptr(), block_tables.stride(0), b, hq, hkv, d, float(scale),
-              out.data_ptr(), num_splits, ws, _stream())
+              out.data_ptr(), num_splits, min_range, ws, _stream())
     return out
 
 
 def attn_decode_fused_qkv(qkv, num_q_heads: int, num_kv_heads: int, q_weight, k_weight, eps: float, positions, cos_sin,
                           k_cache, v_cache, context_lens, block_tables, scale: float, num_splits: int = 0,
-                          max_context: int | None = None) -> torch.Tensor:
+                          max_context: int | None = None, min_range: int = 0, items: dict | None = None) -> torch.Tensor:
     """Decode attention straight from the raw fused qkv rows [B, (Hq+2Hkv)*128]: q/k norm + RoPE + KV store +
     attention in one launch."""
     _gpu_bf16(qkv, q_weight, k_weight, k_cache, v_cache)
     b, d = qkv.shape[0], 128
     assert qkv.stride(1) == 1 and k_cache.is_contiguous() and v_cache.is_contiguous() and positions.dtype == torch.int64
-    if num_splits <= 0:
+    if items is not None:
+        num_splits = items["max_ranges"]
+    elif num_splits <= 0:
         mc = max_context if max_context is not None else block_tables.shape[1] * KV_PAGE
         num_splits = suggest_decode_splits(b, num_kv_heads, mc)
     out = torch.empty(b, num_q_heads, d, dtype=BF16, device=qkv.device)
@@ -277,10 +343,16 @@ def attn_decode_fused_qkv(qkv, num_q_heads: int, num_kv_heads: int, q_weight, k_
         ws_t = torch.empty(_hip.lib().nvh_attn_decode_workspace_bytes(b, num_q_heads, d, num_splits) // 4,
                            dtype=torch.float32, device=qkv.device)
         ws = ws_t.data_ptr()
+    if items is not None:
+        _hip.call("nvh_attn_decode_fused_qkv_items", qkv.data_ptr(), qkv.stride(0), q_weight.data_ptr(), k_weight.data_ptr(),
+                  float(eps), positions.data_ptr(), cos_sin.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                  context_lens.data_ptr(), block_tables.data_ptr(), block_tables.stride(0), b, num_q_heads, num_kv_heads, d,
+                  float(scale), out.data_ptr(), *_items_args(items, b), ws, _stream())
+        return out
     _hip.call("nvh_attn_decode_fused_qkv", qkv.data_ptr(), qkv.stride(0), q_weight.data_ptr(), k_weight.data_ptr(), float(eps),
               positions.data_ptr(), cos_sin.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), context_lens.data_ptr(),
               block_tables.data_ptr(), block_tables.stride(0), b, num_q_heads, num_kv_heads, d, float(scale), out.data_ptr(),
-              num_splits, ws, _stream())
+              num_splits, min_range, ws, _stream())
     return out
 
 

@@ -320,3 +320,74 @@ def test_wide_hidden_decode_uses_split_qkv_and_matches_oracle(tmp_path):
                 st.num_cached_tokens, st.num_new_tokens = s.num_cached_tokens, 1
     finally:
         runner.exit()
+
+
+def test_uneven_contexts_decode_takes_the_work_list(monkeypatch):
+    """Sequences of very different context lengths decoding together.  With the batch treated as a large one (one key
+    range per sequence) and a low long-context threshold, the runner plans a work list for the decode attention:
+    in an eager step, in the captured graph (fixed-capacity list) and for the one-token prefix of a mixed step.
+    Logits against the CPU oracle; eager and graph bit-identical."""
+    import os
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+    monkeypatch.setattr(ModelRunner, "decode_splits", lambda self, bs: 1)
+    monkeypatch.setattr(ModelRunner, "LONG_CONTEXT", 512)
+    monkeypatch.setattr(ModelRunner, "MAX_RANGES", 4)
+    shape = M.ModelShape(**TINY)
+    weights = M.random_weights(shape, seed=0, std=0.05)
+    g = torch.Generator().manual_seed(123)
+    ctxs = [1500, 40, 600, 257, 1]
+    prompts = [torch.randint(0, 1024, (n,), generator=g).tolist() for n in ctxs]
+    fresh = torch.randint(0, 1024, (90,), generator=g).tolist()
+    tables, page = [], 0
+    for n in ctxs + [90]:
+        nb = (n + 1 + 255) // 256
+        tables.append(list(range(page, page + nb)))
+        page += nb
+    os.environ["NANOVLLM_NATIVE"] = "1"
+    outs = {}
+    for which in ("eager", "graph"):
+        cfg = Config(TINY_DIR, max_num_batched_tokens=2048, max_num_seqs=8, max_model_len=2048, enforce_eager=which == "eager",
+                     num_kvcache_blocks=page + 1, chunked_prefill=True)
+        runner = ModelRunner(cfg, 0, [])
+        try:
+            runner.load_weights(hf_named(weights, shape))
+            runner.kv_cache.zero_()
+            oracle = M.RefRunner(shape, weights, page + 1)
+            seen = []
+            orig = runner.native.forward
+            runner.native.forward = lambda *a, **k: (seen.append((k.get("decode_items") is not None, k.get("decode_prefix", 0))),
+                                                      orig(*a, **k))[1]
+            seqs = [seq(p, 0, len(p), t[:(len(p) + 255) // 256]) for p, t in zip(prompts, tables)]
+            states = [M.SeqState(list(p), 0, len(p), list(s.block_table)) for p, s in zip(prompts, seqs)]
+            got = []
+            for step in range(3):
+                logits, _, need = runner.forward_logits(seqs)
+                ref, _ = oracle.run(states)
+                close(logits, ref, atol=3e-2 if step else 5e-2)             # step 0 (packed prefill, tested elsewhere) fills the caches
+                got.append(logits.cpu())
+                toks = ref.float().argmax(-1).tolist()                      # both sides continue with the oracle's ids
+                for s, st, t, tb in zip(seqs, states, toks, tables):
+                    s.num_cached_tokens += s.num_new_tokens
+                    s.append_token(t)
+                    s.num_new_tokens = 1
+                    s.block_table = tb[:(len(s) + 255) // 256]
+                    st.token_ids.append(t)
+                    st.num_cached_tokens, st.num_new_tokens, st.block_table = s.num_cached_tokens, 1, list(s.block_table)
+            if which == "eager":
+                assert seen == [(False, 0), (True, 0), (True, 0)]           # prefill, then two decode steps over a work list
+            else:
+                assert seen == [(False, 0)] and runner.graphs[8].graph_long is not None
+            # mixed step: the five running sequences (one token each) and a fresh prompt
+            seen.clear()
+            batch = seqs + [seq(fresh, 0, 90, tables[5])]
+            logits, _, need = runner.forward_logits(batch)
+            assert seen == [(True, 5)]
+            ref, _ = oracle.run(states + [M.SeqState(list(fresh), 0, 90, list(tables[5]))])
+            close(logits, ref)
+            got.append(logits.cpu())
+            outs[which] = got
+        finally:
+            runner.exit()
+    for a, b in zip(outs["eager"], outs["graph"]):
+        assert torch.equal(a, b)

@@ -332,6 +332,84 @@ def test_attn_decode_merge_kernels_agree(ops):
         assert_close(big[:16], ref, 1.5e-2, 2e-2)
 
 
+def test_attn_decode_adaptive_ranges(ops):
+    """Long and short sequences in one launch: 16 ranges offered, at least 512 keys each.  Sequences of up to 512 keys
+    take one range and must equal the unsplit launch bit for bit; longer ones are merged from partial results."""
+    hq, hkv, d = 16, 8, 128
+    lens_k = [100, 8192, 513, 0, 2049, 512, 1, 3000]
+    b = len(lens_k)
+    q, kc, vc, bt, _, _ = _paged_case(93, [1] * b, lens_k, hq, hkv, num_pages=64)
+    ctx = torch.tensor(lens_k, dtype=torch.int32)
+    scale = d ** -0.5
+    ref = R.attention_decode(q, kc, vc, ctx, bt, scale)
+    one = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=1)
+    got = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=16, min_range=512)
+    assert_close(got, ref, 1.5e-2, 2e-2)
+    for i, n in enumerate(lens_k):
+        if n <= 512:
+            assert torch.equal(got[i], one[i]), f"sequence of {n} keys changed under the long-context plan"
+    assert float(got[3].abs().max()) == 0.0
+    # fused variant: same bits as norm/rope/store followed by the plain kernel, K/V rows stored by the right range
+    qkv = rnd(b, (hq + 2 * hkv) * d, seed=94, scale=1.5)
+    qw, kw = (rnd(d, seed=95).float() * 0.2 + 1).to(BF), (rnd(d, seed=96).float() * 0.2 + 1).to(BF)
+    pos = (ctx.long() - 1).clamp(min=0)
+    slots = torch.tensor([int(bt[i, (n - 1) // 256]) * 256 + (n - 1) % 256 if n > 0 else -1 for i, n in enumerate(lens_k)], dtype=torch.int32)
+    table = dev(R.rope_table(128, 16384, 1e6).squeeze(1).contiguous())
+    qkv_a, kca, vca = dev(qkv.clone()), dev(kc.clone()), dev(vc.clone())
+    ops.qknorm_rope_store_(qkv_a, hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), table, kca, vca, dev(slots))
+    sep = ops.attn_decode(qkv_a[:, :hq * d].view(b, hq, d), kca, vca, dev(ctx), dev(bt), scale, num_splits=16, min_range=512)
+    kcb, vcb = dev(kc.clone()), dev(vc.clone())
+    fused = ops.attn_decode_fused_qkv(dev(qkv.clone()), hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), table, kcb, vcb, dev(ctx), dev(bt),
+                                      scale, num_splits=16, min_range=512)
+    assert_exact(fused, sep)
+    assert_exact(kcb, kca)
+    assert_exact(vcb, vca)
+
+
+@pytest.mark.parametrize("capacity", [0, 24, 11])
+def test_attn_decode_work_list(ops, capacity):
+    """Key ranges named one by one (plan_decode_items): only the long sequences are split.  One-range sequences equal
+    the unsplit launch bit for bit, the rest are merged from partial results; a list squeezed into a fixed capacity
+    (wider ranges, unused slots) gives the same answers; the fused variant equals norm/rope/store + the plain one."""
+    hq, hkv, d = 16, 8, 128
+    lens_k = [100, 8192, 513, 0, 2049, 512, 1, 3000]
+    b = len(lens_k)
+    q, kc, vc, bt, _, _ = _paged_case(93, [1] * b, lens_k, hq, hkv, num_pages=64)
+    ctx = torch.tensor(lens_k, dtype=torch.int32)
+    scale = d ** -0.5
+    plan = ops.plan_decode_items(lens_k, max_ranges=8, range_keys=512, capacity=capacity)
+    covered = {(int(s), int(r)) for s, r in zip(plan["item_seq"], plan["item_range"]) if s >= 0}
+    assert covered == {(s, r) for s in range(b) for r in range(int(plan["seq_active"][s]))}
+    assert all(int(a) * int(c) >= n and int(a) <= 8 for a, c, n in zip(plan["seq_active"], plan["seq_chunk"], lens_k))
+    if capacity:
+        assert plan["item_seq"].size == capacity
+    else:
+        assert int(plan["seq_active"][1]) == 8 and int(plan["seq_active"][2]) == 1
+    items = ops.upload_decode_items(plan, "cuda")
+    ref = R.attention_decode(q, kc, vc, ctx, bt, scale)
+    one = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=1)
+    got = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, items=items)
+    assert_close(got, ref, 1.5e-2, 2e-2)
+    for i in range(b):
+        if int(plan["seq_active"][i]) == 1:
+            assert torch.equal(got[i], one[i]), f"sequence of {lens_k[i]} keys changed under the work list"
+    assert float(got[3].abs().max()) == 0.0
+    qkv = rnd(b, (hq + 2 * hkv) * d, seed=94, scale=1.5)
+    qw, kw = (rnd(d, seed=95).float() * 0.2 + 1).to(BF), (rnd(d, seed=96).float() * 0.2 + 1).to(BF)
+    pos = (ctx.long() - 1).clamp(min=0)
+    slots = torch.tensor([int(bt[i, (n - 1) // 256]) * 256 + (n - 1) % 256 if n > 0 else -1 for i, n in enumerate(lens_k)], dtype=torch.int32)
+    table = dev(R.rope_table(128, 16384, 1e6).squeeze(1).contiguous())
+    qkv_a, kca, vca = dev(qkv.clone()), dev(kc.clone()), dev(vc.clone())
+    ops.qknorm_rope_store_(qkv_a, hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), table, kca, vca, dev(slots))
+    sep = ops.attn_decode(qkv_a[:, :hq * d].view(b, hq, d), kca, vca, dev(ctx), dev(bt), scale, items=items)
+    kcb, vcb = dev(kc.clone()), dev(vc.clone())
+    fused = ops.attn_decode_fused_qkv(dev(qkv.clone()), hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), table, kcb, vcb, dev(ctx), dev(bt),
+                                      scale, items=items)
+    assert_exact(fused, sep)
+    assert_exact(kcb, kca)
+    assert_exact(vcb, vca)
+
+
 def test_attn_decode_strided_q_long_context(ops):
     hq, hkv, d = 16, 8, 128
     lens_k = [8192, 3000]
