@@ -332,3 +332,34 @@ def test_c_flatten_batch_equals_numpy_version():
     _same_fb(MR._hostpath.flatten_batch(seqs, 256), MR._flatten_batch_py(seqs, 256))
     with pytest.raises(IndexError):
         MR._hostpath.flatten_batch([mk(700, 300, 250, [3])], 256)
+
+
+def test_decode_work_list_covers_every_key_exactly_once():
+    """ops.plan_decode_items on random batches: every (sequence, range) appears once, the ranges tile the context
+    (64-key multiples, none empty but a padded row's), no sequence exceeds max_ranges, a fixed capacity is kept by
+    widening ranges, and one-range sequences are exactly those below two ranges' worth of keys."""
+    from nanovllm import ops
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        b = int(rng.integers(1, 300))
+        ctx = rng.integers(0, 400, b)
+        for i in rng.integers(0, b, int(rng.integers(0, 5))):
+            ctx[i] = int(rng.integers(400, 70000))
+        max_ranges = int(rng.choice([1, 4, 32, 256]))
+        capacity = 0 if trial % 2 else b + int(rng.integers(0, 130))
+        plan = ops.plan_decode_items(ctx, max_ranges=max_ranges, capacity=capacity)
+        seq, rg, active, chunk = plan["item_seq"], plan["item_range"], plan["seq_active"], plan["seq_chunk"]
+        assert all(a.dtype == np.int32 for a in (seq, rg, active, chunk))
+        assert seq.size == (capacity or int(active.sum())) and active.size == chunk.size == b
+        used = seq >= 0
+        assert int(used.sum()) == int(active.sum()) and not used[int(used.sum()):].any()      # unused slots at the end
+        pairs = set(zip(seq[used].tolist(), rg[used].tolist()))
+        assert len(pairs) == int(used.sum()) == sum(int(a) for a in active)
+        assert pairs == {(s, r) for s in range(b) for r in range(int(active[s]))}
+        assert (active >= 1).all() and (active <= max_ranges).all() and (chunk % 64 == 0).all() and (chunk >= 64).all()
+        assert (active.astype(np.int64) * chunk >= ctx).all()
+        assert ((active.astype(np.int64) - 1) * chunk < np.maximum(ctx, 1)).all()                # no empty last range
+        first = chunk[seq[used]] * (active[seq[used]] > 1)
+        assert (np.diff(first) <= 0).all()                                                      # longest ranges first
+    plan = ops.plan_decode_items([100, 1023, 1024, 5000], max_ranges=32, range_keys=512)
+    assert plan["seq_active"].tolist() == [1, 1, 2, 9] and plan["seq_chunk"].tolist() == [128, 1024, 512, 576]

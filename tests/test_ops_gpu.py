@@ -366,6 +366,28 @@ def test_attn_decode_adaptive_ranges(ops):
     assert_exact(vcb, vca)
 
 
+@pytest.mark.parametrize("hq,hkv", [(40, 8), (4, 4), (32, 4)])
+def test_attn_decode_work_list_group_sizes(ops, hq, hkv):
+    """The work list with 5, 1 and 8 query heads per kv head, 40 sequences of which three are long."""
+    d = 128
+    g = torch.Generator().manual_seed(hq)
+    lens_k = torch.randint(1, 300, (40,), generator=g).tolist()
+    lens_k[3], lens_k[17], lens_k[39] = 4000, 1531, 2048
+    b = len(lens_k)
+    q, kc, vc, bt, _, _ = _paged_case(7, [1] * b, lens_k, hq, hkv, num_pages=sum((n + 255) // 256 for n in lens_k) + 1)
+    ctx = torch.tensor(lens_k, dtype=torch.int32)
+    scale = d ** -0.5
+    plan = ops.plan_decode_items(lens_k, max_ranges=16, range_keys=256, capacity=b + 64)
+    assert int(plan["seq_active"].sum()) > b + 20
+    items = ops.upload_decode_items(plan, "cuda")
+    ref = R.attention_decode(q, kc, vc, ctx, bt, scale)
+    one = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, num_splits=1)
+    got = ops.attn_decode(dev(q), dev(kc), dev(vc), dev(ctx), dev(bt), scale, items=items)
+    assert_close(got, ref, 1.5e-2, 2e-2)
+    single = torch.from_numpy(plan["seq_active"] == 1)
+    assert torch.equal(got.cpu()[single], one.cpu()[single])
+
+
 @pytest.mark.parametrize("capacity", [0, 24, 11])
 def test_attn_decode_work_list(ops, capacity):
     """Key ranges named one by one (plan_decode_items): only the long sequences are split.  One-range sequences equal
