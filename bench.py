@@ -381,20 +381,23 @@ def main():
         # attention streams pages left behind by the runs above: same bytes and launches as a real batch, no
         # meaningful ids (timing only).
         ctx_sweep = {}
-        for bb, cc in ((min(b, 256), 128), (min(b, 32), 8192)):
+        # The third case is uneven: one long context among short ones (the decode attention runs over a work list).
+        for bb, cc, first in ((min(b, 256), 128, 0), (min(b, 32), 8192, 0), (min(b, 256), 128, 8192)):
             k = 32
             driver.reset()
-            if bb * ((cc + k + 8) // PAGE + 1) > driver.num_pages:
+            lens = [first or cc] + [cc] * (bb - 1)
+            if sum((n + k + 8) // PAGE + 1 for n in lens) > driver.num_pages:
                 continue
-            fake = [driver.new_seq(p) for p in prompts(bb, cc)]
-            for s in fake:
-                s.num_cached_tokens = cc - 1
-                driver.grow(s, cc)
+            fake = [driver.new_seq(p) for n in lens for p in prompts(1, n)]
+            for s, n in zip(fake, lens):
+                s.num_cached_tokens = n - 1
+                driver.grow(s, n)
             d2 = time_decode(driver, fake, k, 4, distributed)
             sb, _, _ = algorithmic_bytes_per_decode_step(hf, [s.num_cached_tokens - k / 2 for s in fake], world)
-            note(f"context sweep B={bb} ctx={cc} done")
-            ctx_sweep[f"B{bb}_ctx{cc}"] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
-                                               hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
+            tag = f"B{bb}_ctx{cc}" + (f"_one{first}" if first else "")
+            note(f"context sweep {tag} done")
+            ctx_sweep[tag] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
+                                  hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
         out["decode_context_sweep"] = ctx_sweep
         if rank == 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(hf)
