@@ -90,6 +90,19 @@ int32_t nvh_qknorm_rope_store(void* qkv, int64_t token_stride, int64_t num_q_hea
                               void* k_cache, void* v_cache, const int32_t* slot_mapping,
                               int64_t num_tokens, nvh_stream_t stream);
 
+/* The fused QKV projection with its q/k epilogue and KV store in one call: Qwen3Attention.forward's
+ * qkv_proj -> q_norm/k_norm -> rotary_emb (models/qwen3.py:183-195) and the store_kvcache half of
+ * Attention.forward (layers/attention.py:93-127, called at :168-249).  qkv[M, (Hq+2Hkv)*128] = x[M,K] w[(Hq+2Hkv)*128, K]^T; rows
+ * raw_rows.. then get nvh_qknorm_rope_store's treatment (positions, slot_mapping index rows of x; caches may be
+ * null), rows below raw_rows stay the plain projection (the decode attention applies the epilogue itself).  Shapes
+ * that take 128x128 GEMM tiles do all of it in the GEMM's epilogue; the others run nvh_gemm_bf16_nt and
+ * nvh_qknorm_rope_store back to back.  Bit-identical either way. */
+int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const void* w, void* qkv, int64_t qkv_row_stride,
+                                int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                const void* q_norm_weight, const void* k_norm_weight, float eps,
+                                const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
+                                void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, nvh_stream_t stream);
+
 /* ---- K7: SiLU(x[:, :I]) * x[:, I:].  layers/activation.py:36-58.  x [rows, 2I] -> y [rows, I]. */
 int32_t nvh_silu_mul(const void* x, void* y, int64_t rows, int64_t inter, nvh_stream_t stream);
 

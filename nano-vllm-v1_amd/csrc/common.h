@@ -86,7 +86,7 @@ __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 // by a 16-lane DPP row: lane c owns elements [8c, 8c+8).  The rotation partner (i +- 64) lives in lane c^8
 // and arrives through a row rotation by 8.  cs_row: fp32 [cos(64) | sin(64)] of the token's position.
 // Used by every kernel that applies the q/k epilogue, so they all produce identical bits.
-__device__ __forceinline__ bf16x8 qknorm_rope_head(bf16x8 x, bf16x8 w, const float* __restrict__ cs_row, int c, float eps) {
+__device__ __forceinline__ bf16x8 qknorm_rope_head_cs(bf16x8 x, bf16x8 w, f32x4 c0, f32x4 c1, f32x4 s0, f32x4 s1, int c, float eps) {
     float v[8];
     float ss = 0.f;
 #pragma unroll
@@ -96,10 +96,6 @@ __device__ __forceinline__ bf16x8 qknorm_rope_head(bf16x8 x, bf16x8 w, const flo
     }
     ss = row16_sum(ss);
     const float inv = 1.0f / sqrtf(ss / 128.0f + eps);
-    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs_row + 8 * (c & 7));
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs_row + 8 * (c & 7) + 4);
-    const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs_row + 64 + 8 * (c & 7));
-    const f32x4 s1 = *reinterpret_cast<const f32x4*>(cs_row + 64 + 8 * (c & 7) + 4);
     bf16x8 out;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -112,4 +108,12 @@ __device__ __forceinline__ bf16x8 qknorm_rope_head(bf16x8 x, bf16x8 w, const flo
         out[j] = f2bf(y);
     }
     return out;
+}
+__device__ __forceinline__ bf16x8 qknorm_rope_head(bf16x8 x, bf16x8 w, const float* __restrict__ cs_row, int c, float eps) {
+    // lane c's cos / sin values: columns 8 (c & 7) .. + 7 of the position's row
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs_row + 8 * (c & 7));
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs_row + 8 * (c & 7) + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs_row + 64 + 8 * (c & 7));
+    const f32x4 s1 = *reinterpret_cast<const f32x4*>(cs_row + 64 + 8 * (c & 7) + 4);
+    return qknorm_rope_head_cs(x, w, c0, c1, s0, s1, c, eps);
 }

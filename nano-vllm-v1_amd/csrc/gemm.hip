@@ -43,10 +43,25 @@ __device__ __forceinline__ void wait_tiles_in_flight(int ahead) {
     }
 }
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU>
+// Epilogue of the fused QKV projection: the output row is [q heads | k heads | v heads] of 128 columns each, a
+// 128-column tile is exactly one head.  Rows below raw_rows are stored as they are (their consumer applies the
+// q/k epilogue itself); the others get per-head RMSNorm + RoPE on q and k heads, and k/v heads also go to their
+// KV-cache slot (slot_mapping null or -1: no store).
+struct QkvEpilogue {
+    const bf16 *q_norm_w, *k_norm_w;
+    const int64_t* positions;
+    const float* cos_sin;
+    bf16 *k_cache, *v_cache;
+    const int32_t* slot_mapping;
+    float eps;
+    int hq, hkv, raw_rows;
+};
+
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
-    bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split) {
+    bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split,
+    QkvEpilogue qe) {
     constexpr int NW = WAVES_N * WAVES_M;                 // waves per workgroup (4; 2 for the skinny decode tiles)
     static_assert(NW == 4 || NW == 2, "2 or 4 waves");
     constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
@@ -140,6 +155,65 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     }
 
     // epilogue: lane holds n = n_base + fq*4 .. +3 of row m = m_base + fr
+    if constexpr (QKV) {
+        // The tile (one head of BM tokens) goes through LDS as bf16 - the rounding point of the separate GEMM - and
+        // is then walked like the stand-alone q/k epilogue kernel: 16 lanes per row, 8 columns per lane, the same
+        // device function, so both routes give the same bits.
+        static_assert(BN == 128 && NW == 4 && !SWIGLU, "one head per tile, 256 threads");
+        constexpr int TS = 136;                                  // LDS row stride in elements (272 B: rows land in different banks)
+        const int c = tid & 15, rr = tid >> 4;
+        const int head = n0 >> 7;                                // block-uniform
+        const bool normed = head < qe.hq + qe.hkv;
+        // cos / sin rows of this thread's 8 tokens: requested before the tile goes through LDS, so their latency
+        // (position, then table row) hides behind the staging
+        f32x4 cs[BM / 16][4];
+        if (normed) {
+#pragma unroll
+            for (int p = 0; p < BM / 16; ++p) {
+                const float* cs_row = qe.cos_sin + qe.positions[min(m0 + p * 16 + rr, M - 1)] * 128 + 8 * (c & 7);
+                cs[p][0] = *reinterpret_cast<const f32x4*>(cs_row);
+                cs[p][1] = *reinterpret_cast<const f32x4*>(cs_row + 4);
+                cs[p][2] = *reinterpret_cast<const f32x4*>(cs_row + 64);
+                cs[p][3] = *reinterpret_cast<const f32x4*>(cs_row + 68);
+            }
+        }
+        __syncthreads();                                         // every wave is done with the last stage
+        bf16* tile = reinterpret_cast<bf16*>(smem);              // [BM][TS]
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = wm * WM + j * 16 + fr, col = wn * WN + i * 16 + fq * 4;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e]);
+                *reinterpret_cast<bf16x4*>(tile + row * TS + col) = o;
+            }
+        __syncthreads();
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>((head < qe.hq ? qe.q_norm_w : qe.k_norm_w) + c * 8);
+        bf16* cache = head < qe.hq ? nullptr : (normed ? qe.k_cache : qe.v_cache);
+        const int kvh = head - qe.hq - (normed ? 0 : qe.hkv);
+        // all epilogue arithmetic first, the stores afterwards
+        bf16x8 outv[BM / 16];
+#pragma unroll
+        for (int p = 0; p < BM / 16; ++p) {
+            const int row = p * 16 + rr, m = min(m0 + row, M - 1);          // rows past M compute on row M-1, store nothing
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TS + c * 8);
+            if (m >= qe.raw_rows && normed) v = qknorm_rope_head_cs(v, wv, cs[p][0], cs[p][1], cs[p][2], cs[p][3], c, qe.eps);   // uniform over a 16-lane row
+            outv[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < BM / 16; ++p) {
+            const int m = m0 + p * 16 + rr;
+            if (m >= M) continue;
+            *reinterpret_cast<bf16x8*>(y + (int64_t)m * y_stride + n0 + c * 8) = outv[p];
+            if (m >= qe.raw_rows && cache != nullptr && qe.slot_mapping != nullptr) {
+                const int64_t slot = qe.slot_mapping[m];
+                if (slot >= 0) *reinterpret_cast<bf16x8*>(cache + (slot * qe.hkv + kvh) * 128 + c * 8) = outv[p];
+            }
+        }
+        return;
+    }
     if constexpr (SWIGLU) {
         // W rows are interleaved in blocks of 16: [gate 16b..16b+15 | up 16b..16b+15], so tile i (even) holds
         // gate and tile i+1 the matching up columns in the same lanes.  y[m][16b + ..] = silu(gate) * up with the
@@ -202,14 +276,15 @@ struct GemmArgs {
     int M, N, K, split_k;
     hipStream_t st;
     bool swiglu;
+    const QkvEpilogue* qkv = nullptr;   // set: the QKV epilogue (128x128 tiles only)
 };
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU>
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false>
 void launch_gemm_nt(const GemmArgs& a) {
     constexpr int smem = STAGES * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool configured = false;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV>;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
@@ -217,13 +292,21 @@ void launch_gemm_nt(const GemmArgs& a) {
     const int ktiles = a.K / BK;
     const int k_per_split = (int)nvh_cdiv(ktiles, a.split_k) * BK;
     dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
-    kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split);
+    kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split,
+                                                       a.qkv ? *a.qkv : QkvEpilogue{});
 }
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
 void launch_gemm(const GemmArgs& a) {
     static const bool no_nt = getenv("NVH_GEMM_NO_NT") != nullptr;   // A/B switch for tuning
     const bool nt = a.M <= BM && !no_nt;
+    if constexpr (BM == 128 && BN == 128 && WAVES_N == 2 && WAVES_M == 2) {
+        if (a.qkv) {
+            if (nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true, false, true>(a);
+            else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, false, true>(a);
+            return;
+        }
+    }
     if (a.swiglu) {
         if (nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true, true>(a);
         else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, true>(a);
@@ -434,6 +517,39 @@ extern "C" int32_t nvh_gemm_swiglu_bf16_nt(const void* x, int64_t x_row_stride, 
     GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, (bf16*)y, nullptr, x_row_stride, y_row_stride, (int)M, (int)N, (int)K, 1,
                (hipStream_t)stream, true};
     return dispatch_gemm(a);
+}
+
+// qkv[M, (Hq + 2 Hkv) * 128] = x W^T followed by the q/k epilogue (per-head RMSNorm, RoPE) and the KV-cache store of
+// rows raw_rows.. - in the GEMM's own epilogue when the shape takes 128 x 128 tiles (one head per tile), otherwise
+// as nvh_gemm_bf16_nt + nvh_qknorm_rope_store.  Both routes give the same bits.
+extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const void* w, void* qkv, int64_t qkv_row_stride,
+                                           int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                           const void* q_norm_weight, const void* k_norm_weight, float eps,
+                                           const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
+                                           void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, nvh_stream_t stream) {
+    NVH_REQUIRE(x && w && qkv && q_norm_weight && k_norm_weight && positions && cos_sin, NVH_EINVAL, "nvh_gemm_qkv_rope_store: null pointer");
+    NVH_REQUIRE(head_dim == 128, NVH_ENOSYS, "nvh_gemm_qkv_rope_store: head_dim %ld unsupported (128 only)", (long)head_dim);
+    NVH_REQUIRE(num_q_heads > 0 && num_kv_heads > 0 && raw_rows >= 0 && raw_rows <= M, NVH_EINVAL, "nvh_gemm_qkv_rope_store: heads / raw_rows out of range");
+    NVH_REQUIRE((k_cache == nullptr) == (v_cache == nullptr), NVH_EINVAL, "nvh_gemm_qkv_rope_store: k_cache and v_cache must both be set or both null");
+    const int64_t N = (num_q_heads + 2 * num_kv_heads) * 128;
+    NVH_REQUIRE(qkv_row_stride % 8 == 0 && nvh_aligned16(qkv) && nvh_aligned16(cos_sin) && nvh_aligned16(q_norm_weight) && nvh_aligned16(k_norm_weight) &&
+                    (!k_cache || (nvh_aligned16(k_cache) && nvh_aligned16(v_cache))),
+                NVH_EINVAL, "nvh_gemm_qkv_rope_store: 16-byte alignment required");
+    static const bool no_fuse = getenv("NVH_NO_FUSED_QKV") != nullptr;            // A/B switch for measurements
+    if (M > 0 && !no_fuse && K > 0 && K % BK == 0 && M < (1 << 30) && x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w) &&
+        pick_tile(M, N, 1) == T128x128 && nvh_cdiv(M, 128) * nvh_cdiv(N, 128) <= 256) {   // one workgroup per CU: the epilogue's registers cost no occupancy
+        const bool store = k_cache && slot_mapping;
+        QkvEpilogue qe{(const bf16*)q_norm_weight, (const bf16*)k_norm_weight, positions, cos_sin, store ? (bf16*)k_cache : nullptr,
+                       store ? (bf16*)v_cache : nullptr, store ? slot_mapping : nullptr, eps, (int)num_q_heads, (int)num_kv_heads, (int)raw_rows};
+        GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, (bf16*)qkv, nullptr, x_row_stride, qkv_row_stride, (int)M, (int)N, (int)K, 1,
+                   (hipStream_t)stream, false, &qe};
+        return dispatch_gemm(a);
+    }
+    const int32_t rc = nvh_gemm_bf16_nt(x, x_row_stride, w, nullptr, qkv, qkv_row_stride, M, N, K, 1, nullptr, stream);
+    if (rc != NVH_OK || M == raw_rows) return rc;
+    return nvh_qknorm_rope_store((bf16*)qkv + raw_rows * qkv_row_stride, qkv_row_stride, num_q_heads, num_kv_heads, q_norm_weight, k_norm_weight,
+                                 eps, positions + raw_rows, cos_sin, max_position, k_cache, v_cache, slot_mapping ? slot_mapping + raw_rows : nullptr,
+                                 M - raw_rows, stream);
 }
 
 // dst rows <- src rows of a merged [gate (I rows) | up (I rows)] weight in the interleaved order above.

@@ -138,21 +138,29 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
                                 pending_slabs ? w.slabs : nullptr, pending_count, stream));
         }
         // ---- attention block
-        if (sq > 1) {
-            FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, nullptr, qkv_n, t, qkv_n, h, sq, w.slabs, stream));
-            FWD(nvh_splitk_reduce(w.slabs, sq, nullptr, w.qkv, qkv_n, t, qkv_n, stream));
-        } else {
-            FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, w.qkv, qkv_n, t, qkv_n, h, 1, nullptr, stream));
-        }
         void* kc = md->k_cache ? md->k_cache[l] : nullptr;
         void* vc = md->v_cache ? md->v_cache[l] : nullptr;
         const bool store = kc && vc && st->slot_mapping;
         static const bool fuse_decode = getenv("NVH_NO_FUSED_DECODE") == nullptr;   // A/B switch for measurements
-        if (st->mode == NVH_MODE_DECODE && store && fuse_decode) {
+        const bool decode_fused = st->mode == NVH_MODE_DECODE && store && fuse_decode;
+        bool qk_done = false;               // the q/k epilogue and the KV store of rows prefix.. already happened
+        if (sq > 1) {
+            FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, nullptr, qkv_n, t, qkv_n, h, sq, w.slabs, stream));
+            FWD(nvh_splitk_reduce(w.slabs, sq, nullptr, w.qkv, qkv_n, t, qkv_n, stream));
+        } else if (!decode_fused && t > prefix && d == 128) {
+            // projection + q/k norm + RoPE + KV store in one call (one launch when the shape takes 128x128 tiles)
+            FWD(nvh_gemm_qkv_rope_store(w.x, h, md->qkv_w[l], w.qkv, qkv_n, t, h, hq, hkv, d, md->q_norm[l], md->k_norm[l], md->eps,
+                                        st->positions, md->cos_sin, md->max_position, store ? kc : nullptr, store ? vc : nullptr,
+                                        store ? st->slot_mapping : nullptr, prefix, stream));
+            qk_done = true;
+        } else {
+            FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, w.qkv, qkv_n, t, qkv_n, h, 1, nullptr, stream));
+        }
+        if (decode_fused) {
             // one launch: q/k norm + RoPE + KV store of the new token + attention
             FWD(decode_attention(md, st, l, w.qkv, qkv_n, kc, vc, b, scale, w.attn, dsplits, w.decode_ws, stream));
         } else {
-            if (t > prefix)
+            if (t > prefix && !qk_done)
                 FWD(nvh_qknorm_rope_store(w.qkv + prefix * qkv_n, qkv_n, hq, hkv, md->q_norm[l], md->k_norm[l], md->eps,
                                           st->positions + prefix, md->cos_sin, md->max_position, store ? kc : nullptr,
                                           store ? vc : nullptr, store ? st->slot_mapping + prefix : nullptr, t - prefix, stream));

@@ -24,6 +24,7 @@ SIGNATURES = {
     "nvh_add_rmsnorm": (i32, [vp, vp, vp, vp, i64, i64, f32, vp, i64, vp]),
     "nvh_rope": (i32, [vp, vp, i64, i64, vp, i64, i64, vp, i64, i64, i64, vp]),
     "nvh_qknorm_rope_store": (i32, [vp, i64, i64, i64, vp, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp]),
+    "nvh_gemm_qkv_rope_store": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp]),
     "nvh_silu_mul": (i32, [vp, vp, i64, i64, vp]),
     "nvh_embedding": (i32, [vp, vp, vp, i64, i64, i64, i64, vp]),
     "nvh_gather_last_rows": (i32, [vp, vp, vp, vp, i64, i64, vp]),

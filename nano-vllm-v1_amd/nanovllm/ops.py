@@ -91,6 +91,23 @@ def qknorm_rope_store_(qkv: torch.Tensor, num_q_heads: int, num_kv_heads: int, q
               slot_mapping.data_ptr() if store else 0, qkv.shape[0], _stream())
 
 
+def linear_qkv_rope_store(x, w, num_q_heads: int, num_kv_heads: int, q_weight, k_weight, eps: float, positions, cos_sin,
+                          k_cache=None, v_cache=None, slot_mapping=None, raw_rows: int = 0) -> torch.Tensor:
+    """qkv [T, (Hq+2Hkv)*128] = x w^T with the q/k epilogue and KV store of rows raw_rows.. applied (in the GEMM's
+    epilogue where the shape allows, as two launches otherwise; same bits)."""
+    _gpu_bf16(x, w, q_weight, k_weight)
+    t, k = x.shape
+    n = (num_q_heads + 2 * num_kv_heads) * 128
+    assert w.shape == (n, k) and w.is_contiguous() and x.stride(1) == 1 and positions.dtype == torch.int64
+    store = k_cache is not None and k_cache.numel() > 0 and slot_mapping is not None and slot_mapping.numel() > 0
+    qkv = torch.empty(t, n, dtype=BF16, device=x.device)
+    _hip.call("nvh_gemm_qkv_rope_store", x.data_ptr(), x.stride(0), w.data_ptr(), qkv.data_ptr(), n, t, k, num_q_heads,
+              num_kv_heads, 128, q_weight.data_ptr(), k_weight.data_ptr(), float(eps), positions.data_ptr(), cos_sin.data_ptr(),
+              cos_sin.shape[0], k_cache.data_ptr() if store else 0, v_cache.data_ptr() if store else 0,
+              slot_mapping.data_ptr() if store else 0, raw_rows, _stream())
+    return qkv
+
+
 def store_kvcache(key, value, k_cache, v_cache, slot_mapping) -> None:
     _gpu_bf16(key, value, k_cache, v_cache)
     n, h, d = key.shape

@@ -137,6 +137,44 @@ def test_add_rmsnorm_from_splitk_slabs(ops):
     assert_close(nres, rr, 2e-2, 2e-2)
 
 
+@pytest.mark.parametrize("t,raw,store", [(1024, 0, True), (900, 37, True), (1024, 1024, True), (770, 5, False), (100, 3, True)])
+def test_fused_qkv_projection_equals_separate_launches(ops, t, raw, store):
+    """QKV projection with the q/k epilogue and the KV store in the GEMM's epilogue (128x128 tiles, from 769 rows on)
+    against GEMM + qknorm_rope_store on the rows past `raw`: same bits in qkv and in both caches; the oracle's
+    per-head norm + RoPE on one of the rows."""
+    hq, hkv, d, k = 16, 8, 128, 1024
+    n = (hq + 2 * hkv) * d
+    x, w = rnd(t, k, seed=51), rnd(n, k, seed=52, scale=0.05)
+    qw, kw = (rnd(d, seed=53).float() * 0.2 + 1).to(BF), (rnd(d, seed=54).float() * 0.2 + 1).to(BF)
+    g = torch.Generator().manual_seed(55)
+    pos = torch.randint(0, 4000, (t,), generator=g)
+    slots = torch.randperm(5 * 256, generator=g)[:t].to(torch.int32)
+    slots[t // 2] = -1
+    table = dev(R.rope_table(128, 4096, 1e6).squeeze(1).contiguous())
+    kc0, vc0 = rnd(5, 256, hkv, d, seed=56), rnd(5, 256, hkv, d, seed=57)
+    # separate launches
+    qkv_a = ops.linear(dev(x), dev(w))
+    kca, vca = dev(kc0.clone()), dev(vc0.clone())
+    if raw < t:
+        ops.qknorm_rope_store_(qkv_a[raw:], hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos[raw:]), table, kca if store else None,
+                               vca if store else None, dev(slots[raw:]) if store else None)
+    # one call
+    kcb, vcb = dev(kc0.clone()), dev(vc0.clone())
+    qkv_b = ops.linear_qkv_rope_store(dev(x), dev(w), hq, hkv, dev(qw), dev(kw), 1e-6, dev(pos), table, kcb if store else None,
+                                      vcb if store else None, dev(slots) if store else None, raw_rows=raw)
+    assert_exact(qkv_b, qkv_a)
+    assert_exact(kcb, kca)
+    assert_exact(vcb, vca)
+    if raw < t:
+        r = t - 1
+        y = R.linear(x[r:r + 1], w)
+        q = R.rms_norm(y[:, :hq * d].reshape(1, hq, d), qw, 1e-6)
+        kk = R.rms_norm(y[:, hq * d:(hq + hkv) * d].reshape(1, hkv, d), kw, 1e-6)
+        qr, kr = R.rope(pos[r:r + 1], q, kk, R.rope_table(128, 4096, 1e6))
+        assert_close(qkv_b[r, :hq * d].view(hq, d), qr[0], 3e-2, 3e-2)
+        assert_close(qkv_b[r, hq * d:(hq + hkv) * d].view(hkv, d), kr[0], 3e-2, 3e-2)
+
+
 def test_store_kvcache_strided_and_skips(ops):
     t, hq, hkv, d = 37, 4, 2, 128
     qkv = rnd(t, (hq + 2 * hkv) * d, seed=8)
