@@ -61,7 +61,7 @@ template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool 
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split,
-    QkvEpilogue qe) {
+    QkvEpilogue qe, bool wide_store) {
     constexpr int NW = WAVES_N * WAVES_M;                 // waves per workgroup (4; 2 for the skinny decode tiles)
     static_assert(NW == 4 || NW == 2, "2 or 4 waves");
     constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
@@ -241,6 +241,40 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         }
         return;
     }
+    if constexpr (BN == 128 && NW == 4 && BM >= 64) {
+        // full 128-column tiles with a bf16 result: through LDS, so every lane stores 16 contiguous bytes and a row
+        // of the tile leaves as one 256-B line (the fragment layout would store 8 B per lane, 32 B per row piece)
+        if (partials == nullptr && n0 + BN <= N && wide_store) {                 // block-uniform
+            constexpr int TS = 136;
+            __syncthreads();                                     // every wave is done with the last stage
+            bf16* tile = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int col = wn * WN + i * 16 + fq * 4;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (bias != nullptr) {
+                    const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n0 + col);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e] + bv[e]);
+                    *reinterpret_cast<bf16x4*>(tile + (wm * WM + j * 16 + fr) * TS + col) = o;
+                }
+            }
+            __syncthreads();
+            const int c = tid & 15, rr = tid >> 4;
+#pragma unroll
+            for (int p = 0; p < BM / 16; ++p) {
+                const int row = p * 16 + rr, m = m0 + row;
+                if (m < M) *reinterpret_cast<bf16x8*>(y + (int64_t)m * y_stride + n0 + c * 8) = *reinterpret_cast<const bf16x8*>(tile + row * TS + c * 8);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
         const int n = n0 + wn * WN + i * 16 + fq * 4;
@@ -290,10 +324,13 @@ void launch_gemm_nt(const GemmArgs& a) {
         configured = true;
     }
     const int ktiles = a.K / BK;
+    static const bool no_wide = getenv("NVH_GEMM_NO_WIDE_STORE") != nullptr;   // A/B switch for measurements
+    // wide stores need 16-byte aligned output rows and the staging tile inside the kernel's LDS
+    const bool wide = !no_wide && a.ys % 8 == 0 && nvh_aligned16(a.y) && smem >= BM * 136 * 2;
     const int k_per_split = (int)nvh_cdiv(ktiles, a.split_k) * BK;
     dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
     kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split,
-                                                       a.qkv ? *a.qkv : QkvEpilogue{});
+                                                       a.qkv ? *a.qkv : QkvEpilogue{}, wide);
 }
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
