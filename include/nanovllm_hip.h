@@ -95,8 +95,9 @@ int32_t nvh_qknorm_rope_store(void* qkv, int64_t token_stride, int64_t num_q_hea
  * Attention.forward (layers/attention.py:93-127, called at :168-249).  qkv[M, (Hq+2Hkv)*128] = x[M,K] w[(Hq+2Hkv)*128, K]^T; rows
  * raw_rows.. then get nvh_qknorm_rope_store's treatment (positions, slot_mapping index rows of x; caches may be
  * null), rows below raw_rows stay the plain projection (the decode attention applies the epilogue itself).  Shapes
- * that take 128x128 GEMM tiles do all of it in the GEMM's epilogue; the others run nvh_gemm_bf16_nt and
- * nvh_qknorm_rope_store back to back.  Bit-identical either way. */
+ * that take 128x128 GEMM tiles in a grid of at most 256 (769..1024 rows of the Qwen3-0.6B projection) do all of it
+ * in the GEMM's epilogue; the others run nvh_gemm_bf16_nt and nvh_qknorm_rope_store back to back.  Bit-identical
+ * either way. */
 int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const void* w, void* qkv, int64_t qkv_row_stride,
                                 int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
                                 const void* q_norm_weight, const void* k_norm_weight, float eps,
