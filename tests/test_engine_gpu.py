@@ -159,3 +159,37 @@ def test_generate_text_prompts_with_a_tokenizer(weights, tmp_path):
         assert again[0]["token_ids"] == [first]
     finally:
         llm.exit()
+
+
+def test_generate_uneven_contexts_over_the_work_list(weights, monkeypatch):
+    """A long prompt next to short ones through `LLM.generate`, with the batch treated as a large one and a low
+    long-context threshold, so every decode step (graph replay, fixed-capacity work list) and the one-token prefix of
+    every mixed step plan a work list; sequences finish at different times (the graph bucket shrinks) and cross page
+    boundaries.  Every generated id is checked against the oracle by teacher forcing."""
+    from nanovllm import SamplingParams
+    from nanovllm.engine.model_runner import ModelRunner
+    monkeypatch.setattr(ModelRunner, "decode_splits", lambda self, bs: 1)
+    monkeypatch.setattr(ModelRunner, "LONG_CONTEXT", 300)
+    monkeypatch.setattr(ModelRunner, "MAX_RANGES", 4)
+    from nanovllm.engine import model_runner as MR
+    plans = []
+    plan_items = MR._DecodeGraph._plan_items
+    monkeypatch.setattr(MR._DecodeGraph, "_plan_items", lambda self: (plans.append(self.bs), plan_items(self))[1])
+    llm = make_llm(weights, max_num_batched_tokens=700, num_kvcache_blocks=16)
+    try:
+        captured = len(plans)                                  # one plan per captured graph (its initial list)
+        planned = []
+        orig = llm.model_runner.native.forward
+        llm.model_runner.native.forward = lambda *a, **k: (planned.append(k.get("decode_items") is not None), orig(*a, **k))[1]
+        assert all(g.graph_long is not None for g in llm.model_runner.graphs.values())
+        prompts = prompts_of([1500, 20, 250, 5, 600], seed=9)
+        sps = [SamplingParams(temperature=1e-9, max_tokens=n, ignore_eos=True) for n in (30, 12, 20, 40, 8)]
+        outs = llm.generate(prompts, sps, use_tqdm=False)
+        assert [len(o["token_ids"]) for o in outs] == [30, 12, 20, 40, 8]
+        exact = sum(check_teacher_forced(weights, p, o["token_ids"]) for p, o in zip(prompts, outs))
+        assert exact >= 107                                    # 110 generated ids; a few bf16 ties at most
+        assert any(planned), "no eager step planned a work list"
+        assert len(plans) - captured >= 20 and len(set(plans[captured:])) >= 2, "graph replays over a work list, in two buckets at least"
+        assert llm.is_finished() and not llm.scheduler.block_manager.used_block_ids
+    finally:
+        llm.exit()
