@@ -34,6 +34,18 @@ def test_cabi_exports_every_declared_symbol():
     assert rc == -22 and b"null pointer" in lib.nvh_last_error()
     rc = lib.nvh_rope(ctypes.c_void_p(16), ctypes.c_void_p(16), 0, 1, ctypes.c_void_p(16), 0, 1, ctypes.c_void_p(16), 1, 1, 64, None)
     assert rc == -38 and b"head_dim" in lib.nvh_last_error()
+    p = ctypes.c_void_p(4096)                            # a well-aligned non-null address; never dereferenced
+    # a work list shorter than the batch, or whose range count differs from the workspace's
+    rc = lib.nvh_attn_decode_items(p, 4096, p, p, p, p, 8, 4, 16, 8, 128, 0.1, p, p, p, p, p, 2, 4, p, None)
+    assert rc == -22 and b"work list" in lib.nvh_last_error()
+    rc = lib.nvh_attn_decode_items(p, 4096, p, p, p, p, 8, 4, 16, 8, 128, 0.1, p, p, p, p, p, 6, 4, None, None)
+    assert rc == -22 and b"workspace" in lib.nvh_last_error()
+    rc = lib.nvh_gemm_qkv_rope_store(p, 1024, p, p, 4096, 8, 1024, 16, 8, 64, p, p, 1e-6, p, p, 4096, None, None, None, 0, None)
+    assert rc == -38 and b"head_dim" in lib.nvh_last_error()
+    rc = lib.nvh_gemm_qkv_rope_store(p, 1024, p, p, 4096, 8, 1024, 16, 8, 128, p, p, 1e-6, p, p, 4096, None, None, None, 9, None)
+    assert rc == -22 and b"raw_rows" in lib.nvh_last_error()
+    rc = lib.nvh_gemm_qkv_rope_store(p, 1024, p, p, 4096, 8, 1024, 16, 8, 128, p, p, 1e-6, p, p, 4096, p, None, None, 0, None)
+    assert rc == -22 and b"k_cache and v_cache" in lib.nvh_last_error()
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
