@@ -380,7 +380,10 @@ class ModelRunner:
         prefix = fb.get("decode_prefix", 0) if mode == MODE_PAGED else 0
         tails = fb.get("tails", (None, None))
         if prefix:
-            splits = self.decode_plan(prefix, int(fb["context_lens"][:prefix].max()))[0]
+            longest = int(fb["context_lens"][:prefix].max())
+            splits, listed = self.decode_plan(prefix, longest)
+            if not listed:                  # an eager launch: ranges for the contexts at hand, not for max_model_len
+                splits = ops.suggest_decode_splits(prefix, self.model.model.layers[0].self_attn.num_kv_heads, longest)
         items = fb.get("items")
         assert items is None or splits == self.MAX_RANGES
         return self.native.forward(input_ids, positions, mode=mode, batch=bs, cu_seqlens_q=ctx.cu_seqlens_q,
