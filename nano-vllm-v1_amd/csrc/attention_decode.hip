@@ -249,16 +249,9 @@ __device__ __forceinline__ int active_ranges(const int32_t* ctx_lens, int64_t bh
     return active > 1 ? active : -1;
 }
 
-__global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
-                                                                  const float* __restrict__ ws_ml,
-                                                                  bf16* __restrict__ out, int num_splits, int64_t rows,
-                                                                  const int32_t* __restrict__ ctx_lens, int hq, int min_range,
-                                                                  const int32_t* __restrict__ seq_active) {
-    const int lane = threadIdx.x & 63;
-    const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (bh >= rows) return;
-    const int active = active_ranges(ctx_lens, bh, hq, num_splits, min_range, seq_active);
-    if (active < 0) return;
+// One wave merges the `active` partial results of row bh (one query head of one sequence).
+__device__ __forceinline__ void merge_row_wave(const float* __restrict__ ws_acc, const float* __restrict__ ws_ml, bf16* __restrict__ out,
+                                               int num_splits, int64_t bh, int active, int lane) {
     const f32x2* ml = reinterpret_cast<const f32x2*>(ws_ml) + bh * num_splits;
     float m_loc = -INFINITY;
     for (int s = lane; s < active; s += 64) {
@@ -297,6 +290,33 @@ __global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* _
     const float a0 = (A[0][0] + A[1][0]) + (A[2][0] + A[3][0]), a1 = (A[0][1] + A[1][1]) + (A[2][1] + A[3][1]);
     bf16x2 o = {f2bf(a0 * inv), f2bf(a1 * inv)};
     *reinterpret_cast<bf16x2*>(out + bh * 128 + lane * 2) = o;
+}
+
+__global__ __launch_bounds__(256) void attn_decode_combine_kernel(const float* __restrict__ ws_acc,
+                                                                  const float* __restrict__ ws_ml,
+                                                                  bf16* __restrict__ out, int num_splits, int64_t rows,
+                                                                  const int32_t* __restrict__ ctx_lens, int hq, int min_range,
+                                                                  const int32_t* __restrict__ seq_active) {
+    const int lane = threadIdx.x & 63;
+    const int64_t bh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= rows) return;
+    const int active = active_ranges(ctx_lens, bh, hq, num_splits, min_range, seq_active);
+    if (active < 0) return;
+    merge_row_wave(ws_acc, ws_ml, out, num_splits, bh, active, lane);
+}
+
+// Work-list launches: one workgroup per sequence, one wave per query head (16 at a time).  Nearly every sequence of
+// such a batch has a single range and nothing to merge, so its workgroup leaves at once - a quarter as many
+// workgroups to dispatch as with four rows each.
+__global__ __launch_bounds__(1024) void attn_decode_combine_seq_kernel(const float* __restrict__ ws_acc,
+                                                                       const float* __restrict__ ws_ml,
+                                                                       bf16* __restrict__ out, int num_splits, int hq,
+                                                                       const int32_t* __restrict__ seq_active) {
+    const int active = min(seq_active[blockIdx.x], num_splits);
+    if (active <= 1) return;                                       // block-uniform
+    const int lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+    for (int h = threadIdx.x >> 6; h < hq; h += waves)
+        merge_row_wave(ws_acc, ws_ml, out, num_splits, (int64_t)blockIdx.x * hq + h, active, lane);
 }
 
 __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const float* __restrict__ ws_acc,
@@ -364,7 +384,9 @@ __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const floa
 
 int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits,
                                 const int32_t* ctx_lens, int hq, int min_range, const int32_t* seq_active, hipStream_t st) {
-    if (rows <= 2048 && num_splits <= 256)
+    if (seq_active != nullptr && rows / hq > 16)
+        attn_decode_combine_seq_kernel<<<(unsigned)(rows / hq), 64 * (hq < 16 ? hq : 16), 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, hq, seq_active);
+    else if (rows <= 2048 && num_splits <= 256)
         attn_decode_combine_row_kernel<<<(unsigned)rows, 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, ctx_lens, hq, min_range, seq_active);
     else
         attn_decode_combine_kernel<<<(unsigned)nvh_cdiv(rows, 4), 256, 0, st>>>(ws_acc, ws_ml, (bf16*)out, num_splits, rows, ctx_lens, hq, min_range,
