@@ -10,7 +10,8 @@ B sequences that each decode one token at ~1024 tokens of context (synthetic tok
 random-init weights of the Qwen3-0.6B architecture).  `value` = B * steps / wall time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--context C]
-  N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  N > 1: either as typed (the script starts its N ranks itself through torch.distributed.run) or under a launcher:
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.  Extra keys: `roofline` (dominant kernel, HIP-event timed),
 `step_roofline` (all algorithmic bytes of a step / step time), `prefill` (1024-token chunks),
@@ -28,6 +29,40 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "nano-vllm-v1_amd"))
 sys.path.insert(0, str(ROOT))
+
+# HIP IPC between the rank processes (the tensor-parallel exchange) needs the runtime's legacy IPC mode off on
+# dmabuf-only hosts; it must be in the environment before the first HIP call and is inherited by child ranks.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def launch_ranks_if_needed(argv):
+    """`python bench.py --gpus N` typed as is (no launcher, WORLD_SIZE unset): start the N ranks as child processes
+    through torch.distributed.run - the same command line a launcher would use - BEFORE this process touches the
+    GPU, relay their output (rank 0 prints the JSON line) and exit with the launcher's status.  The reference starts
+    its own ranks as well (engine/llm_engine.py:101-111)."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sock:                      # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    launch_ranks_if_needed(sys.argv[1:])
 
 import torch
 import torch.distributed as dist
@@ -256,8 +291,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: for --gpus N > 1 launch with python -m torch.distributed.run --nproc-per-node N")
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
     # Rehearsal on a one-GPU box: NANOVLLM_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 with gloo as the
     # control plane (RCCL refuses two ranks on one device); the data path is the xGMI exchange either way.
     share_device = os.environ.get("NANOVLLM_BENCH_SHARE_DEVICE", "0") == "1"
@@ -329,8 +363,12 @@ def main():
                                   weight_bytes=int(w_bytes), kv_bytes_per_context_token=int(kv_tok)),
                prefill=prefill, init_s=round(init_s, 1))
     if distributed:
+        from nanovllm import comm as comm_mod
         out["tp_exchange"] = ("xgmi peer all-reduce (one kernel per projection, inside the native step and its hipGraph)"
                               if runner.comm is not None else "torch.distributed (RCCL) between operator modules")
+        out["comm_fallback_reason"] = comm_mod.fallback_reason      # None: the peer exchange passed its start-up check
+        out["decode_graphs"] = bool(runner.graphs)
+        out["native_executor"] = runner.native is not None
         if share_device:
             out["config"]["rehearsal"] = "all ranks share cuda:0; not a scaling measurement"
     out["roofline"] = kernel_roofline(runner, seqs, iters=4)

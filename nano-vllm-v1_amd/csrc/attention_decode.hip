@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
         split = items.item_range[blockIdx.z];
         num_splits = items.max_ranges;
         ctx = ctx_lens[b];
-        chunk = max(items.seq_chunk[b], 64);                 // a malformed list may drop keys, never leave the buffers
+        chunk = max(items.seq_chunk[b] & ~63, 64);           // whole 64-key trips: a malformed list may drop keys, never leave a page
         active = min(items.seq_active[b], num_splits);
         if (split < 0) return;
     } else {                                                 // uniform grid

@@ -52,7 +52,12 @@ namespace {
 // Epoch e has been reached by every rank's block blockIdx.x once this returns.  `release`: this block wrote
 // data the peers will read after the barrier.
 __device__ __forceinline__ void comm_barrier(const CommDev& c, uint32_t e, bool release) {
-    if (release) __threadfence_system();
+    // Every thread that stored data for the peers fences at system scope.  When an EARLIER kernel of the stream
+    // produced the data in place (a GEMM writing into the staging area), two things make it visible: the region is
+    // allocated hipDeviceMallocUncached, so stores to it bypass the L2s and have reached memory when that kernel's
+    // waves retire, and one lane still issues a system-scope fence here so the flag store below is ordered after
+    // whatever this XCD's L2 might hold (no reliance on the scope of the fence between two graph nodes).
+    if (release || threadIdx.x == 0) __threadfence_system();
     __syncthreads();
     const int t = threadIdx.x;
     if (t < c.world) {

@@ -135,8 +135,11 @@ __global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restric
                 constexpr float LN2 = 0.6931471805599453f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float un = ((float)(c[e] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-                    const float ex = -LN2 * __builtin_amdgcn_logf(un);                      // Exp(1) sample, > 0
+                    // 23 random bits -> u = (k + 1/2) * 2^-23: every step is exact in fp32 and u stays inside
+                    // [2^-24, 1 - 2^-24], so E = -ln(u) is never 0; the clamp is the one the reference applies
+                    // (layers/sampler.py:80, clamp_min_(1e-10)).
+                    const float un = (float)(c[e] >> 9) * 0x1p-23f + 0x1p-24f;
+                    const float ex = fmaxf(-LN2 * __builtin_amdgcn_logf(un), 1e-10f);       // Exp(1) sample
                     sc[e] = __builtin_fmaf(v[u][e], inv_t, -LN2 * __builtin_amdgcn_logf(ex));
                 }
             } else {

@@ -46,7 +46,9 @@ class Config:
     chunked_prefill: bool = False
 
     def __post_init__(self):
-        assert self.kvcache_block_size % 256 == 0
+        # the reference asserts a multiple of 256 (config.py:82) but its Sequence.block_size is the constant 256
+        # (engine/sequence.py:73) and every kernel here indexes 256-token pages: any other size would read wrong keys
+        assert self.kvcache_block_size == 256, "the KV page is 256 tokens (kvcache_block_size must stay 256)"
         assert 1 <= self.tensor_parallel_size <= 8
         if self.hf_config is None:
             self.hf_config = load_hf_config(self.model)

@@ -435,7 +435,7 @@ class ModelRunner:
         """The captured graph that fits this step, or None (eager)."""
         bs = len(fb["context_lens"])
         if (self.enforce_eager or not self.graphs or fb["block_tables"] is None or fb["max_seqlen_q"] != 1
-                or fb["input_ids"].size != bs or bs > self.graph_bs[-1]
+                or fb["input_ids"].size != bs or fb["need"].size != bs or bs > self.graph_bs[-1]
                 or fb["block_tables"].shape[1] > self.graph_width):
             return None
         graph = self.graphs[next(x for x in self.graph_bs if x >= bs)]

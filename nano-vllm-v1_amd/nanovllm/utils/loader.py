@@ -19,32 +19,58 @@ def default_weight_loader(param: nn.Parameter, loaded_weight: torch.Tensor):
     param.data.copy_(loaded_weight)
 
 
-def load_tensors(model: nn.Module, named_tensors) -> int:
-    """Feed (name, tensor) pairs through the per-parameter loaders; returns how many were consumed."""
+# Checkpoint entries that have no parameter of their own: the output projection of a tied model
+# (models/qwen3.py:481-482 aliases it to the embedding) and rotary tables some exporters include.
+_SKIPPABLE = ("lm_head.weight", "rotary_emb.inv_freq")
+
+
+def load_tensors(model: nn.Module, named_tensors, loaded: set | None = None) -> int:
+    """Feed (name, tensor) pairs through the per-parameter loaders; returns how many were consumed.
+    A name that matches no parameter raises (as the reference's get_parameter does, utils/loader.py:81-88)
+    unless it is one of the entries a tied / exported checkpoint may carry without a parameter behind it.
+    ``loaded`` collects the parameter names that received data."""
     packed = getattr(model, "packed_modules_mapping", {})
     params = dict(model.named_parameters())
     n = 0
     for name, tensor in named_tensors:
         for key, (target, shard_id) in packed.items():
             if key in name:
-                param = params[name.replace(key, target)]
+                pname = name.replace(key, target)
+                if pname not in params:
+                    raise KeyError(f"checkpoint tensor {name!r} maps to {pname!r}, which is not a parameter of the model")
+                param = params[pname]
                 param.weight_loader(param, tensor, shard_id)
                 break
         else:
-            if name not in params:          # e.g. lm_head.weight of a tied checkpoint
-                continue
-            param = params[name]
+            if name not in params:
+                if name.endswith(_SKIPPABLE):
+                    continue
+                raise KeyError(f"checkpoint tensor {name!r} matches no parameter of the model")
+            pname, param = name, params[name]
             getattr(param, "weight_loader", default_weight_loader)(param, tensor)
+        if loaded is not None:
+            loaded.add(pname)
         n += 1
     return n
+
+
+def check_all_loaded(model: nn.Module, loaded: set) -> None:
+    """Every parameter must have received data; a tied lm_head shares the embedding's storage."""
+    seen_ptrs = {p.data_ptr() for name, p in model.named_parameters() if name in loaded}
+    missing = [name for name, p in model.named_parameters() if name not in loaded and p.data_ptr() not in seen_ptrs]
+    if missing:
+        raise RuntimeError(f"{len(missing)} parameters were not loaded from the checkpoint: {missing[:8]}"
+                           f"{' ...' if len(missing) > 8 else ''}")
 
 
 def load_model(model: nn.Module, path: str) -> int:
     from safetensors import safe_open
     n = 0
+    loaded: set = set()
     for file in sorted(glob(os.path.join(path, "*.safetensors"))):
         with safe_open(file, "pt", "cpu") as f:
-            n += load_tensors(model, ((name, f.get_tensor(name)) for name in f.keys()))
+            n += load_tensors(model, ((name, f.get_tensor(name)) for name in f.keys()), loaded)
+    check_all_loaded(model, loaded)
     return n
 
 

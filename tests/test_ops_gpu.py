@@ -580,3 +580,18 @@ def test_argmax_and_sampling(ops):
     assert torch.equal(draws, again)                          # counter-based: reproducible
     other = ops.sample(dev(rows), dev(t), seed=1234, offset=6).cpu()
     assert not torch.equal(draws, other)
+
+
+def test_sample_noise_is_never_zero(ops):
+    """The generated Exp(1) noise must stay strictly positive: a zero would make -log(E) = +inf and hand the row to a
+    random column whatever its logit (2^-24 per element before the fix: about one token in a hundred at this
+    vocabulary).  19 million draws per call, four calls; column 7 leads by a margin (z/T = 200) that no finite noise
+    term can overturn (-log E <= 17 for E >= 2^-24), so every sampled id must be 7."""
+    rows, vocab = 128, 151936
+    logits = torch.zeros(rows, vocab, dtype=torch.float32)
+    logits[:, 7] = 10.0
+    temps = torch.full((rows,), 0.05)
+    dl, dt = dev(logits), dev(temps)
+    for offset in range(4):
+        ids = ops.sample(dl, dt, seed=1234, offset=offset)
+        assert ids.cpu().tolist() == [7] * rows, f"offset {offset}: {(ids.cpu() != 7).sum().item()} rows left the leading column"
