@@ -208,6 +208,21 @@ int32_t nvh_attn_decode_fused_qkv_items(const void* qkv, int64_t token_stride, c
                                         float softmax_scale, void* out, const int32_t* item_seq, const int32_t* item_range,
                                         const int32_t* seq_active, const int32_t* seq_chunk, int64_t num_items,
                                         int32_t max_ranges, void* workspace, nvh_stream_t stream);
+/* nvh_attn_decode for callers that cannot allocate (code under hipGraph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same kernels, same arguments and same bits as nvh_attn_decode,
+ * but the per-range partial results go to a fixed device array inside the library instead of a caller workspace; the
+ * call performs no allocation of any kind.  Limit: nvh_attn_decode_workspace_bytes(batch, Hq, D, num_splits) must not
+ * exceed nvh_attn_decode_noalloc_max_bytes() (8 MiB; e.g. 32 sequences x 16 heads x 32 ranges), larger requests fail
+ * with NVH_EINVAL.  Every GPU the library runs on holds its own copy of the array until the process ends; all calls
+ * on one GPU share it, so calls that overlap there (two streams) race.  The array's device address is looked up on the
+ * first call on a GPU, or by nvh_device_check() of the current device. */
+int32_t nvh_attn_decode_noalloc(const void* q, int64_t q_token_stride,
+                                const void* k_cache, const void* v_cache,
+                                const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                float softmax_scale, void* out, int32_t num_splits, int32_t min_range_keys,
+                                nvh_stream_t stream);
+int64_t nvh_attn_decode_noalloc_max_bytes(void);
 int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_heads, int64_t head_dim, int32_t num_splits);
 int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int64_t max_context);
 

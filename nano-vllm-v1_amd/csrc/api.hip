@@ -22,5 +22,9 @@ extern "C" int32_t nvh_device_check(int32_t device_index) {
     NVH_REQUIRE(e == hipSuccess, NVH_ENODEV, "nvh_device_check: hipGetDeviceProperties(%d): %s", device_index, hipGetErrorString(e));
     NVH_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, NVH_ENODEV,
                 "nvh_device_check: device %d is %s; this library contains gfx950 code only", device_index, prop.gcnArchName);
+    // set-up for nvh_attn_decode_noalloc: resolve this GPU's copy of its built-in array now when the checked device is
+    // the current one (otherwise the entry point does it on its first call there)
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device_index) return nvh_noalloc_scratch(nullptr);
     return NVH_OK;
 }

@@ -484,6 +484,57 @@ extern "C" int32_t nvh_attn_decode(const void* q, int64_t q_token_stride, const 
     return launch_decode<false>("nvh_attn_decode", a, FusedQkv{});
 }
 
+// ---- nvh_attn_decode for callers that cannot allocate: the per-range partial results live in a device array of the
+// code object instead of a caller workspace.  Every GPU the library runs on holds its own copy of the array (at its own
+// address) until the process ends; calls that overlap on one GPU share it and race.  Nothing in it has to start at
+// zero: the merge kernel reads exactly the records the attention kernel of the same call wrote.
+#define NVH_NOALLOC_SCRATCH_FLOATS (2 * 1024 * 1024)          /* 8 MiB */
+static __device__ __align__(256) float scratch[NVH_NOALLOC_SCRATCH_FLOATS];
+namespace {
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};                       // device address of `scratch` on each GPU, resolved once
+}  // namespace
+
+// Resolves the current device's copy of the array (no allocation, no stream work).  Host code must never pass the
+// array's name to a kernel: the name is a host-side stand-in, only this address is device memory.
+int32_t nvh_noalloc_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    NVH_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, NVH_ELAUNCH, "nvh_attn_decode_noalloc: hipGetDevice: %s (device %d)",
+                hipGetErrorString(e), dev);
+    if (g_scratch_ptr[dev] == nullptr) {
+        float* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        NVH_REQUIRE(e == hipSuccess && p != nullptr, NVH_ELAUNCH, "nvh_attn_decode_noalloc: hipGetSymbolAddress on device %d: %s", dev,
+                    hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    if (out) *out = g_scratch_ptr[dev];
+    return NVH_OK;
+}
+
+extern "C" int64_t nvh_attn_decode_noalloc_max_bytes(void) { return (int64_t)NVH_NOALLOC_SCRATCH_FLOATS * (int64_t)sizeof(float); }
+
+extern "C" int32_t nvh_attn_decode_noalloc(const void* q, int64_t q_token_stride, const void* k_cache, const void* v_cache,
+                                           const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
+                                           int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                           float softmax_scale, void* out, int32_t num_splits, int32_t min_range_keys,
+                                           nvh_stream_t stream) {
+    NVH_REQUIRE(batch >= 0 && num_q_heads > 0 && num_splits >= 1, NVH_EINVAL, "nvh_attn_decode_noalloc: batch / heads / num_splits out of range");
+    const int64_t need = nvh_attn_decode_workspace_bytes(batch, num_q_heads, head_dim, num_splits);
+    NVH_REQUIRE(need <= nvh_attn_decode_noalloc_max_bytes(), NVH_EINVAL,
+                "nvh_attn_decode_noalloc: batch %ld x %ld heads x %d key ranges needs %ld bytes of partial results, the built-in "
+                "array holds %ld; use fewer ranges or nvh_attn_decode with a workspace",
+                (long)batch, (long)num_q_heads, num_splits, (long)need, (long)nvh_attn_decode_noalloc_max_bytes());
+    float* ws = nullptr;
+    const int32_t rc = nvh_noalloc_scratch(&ws);
+    if (rc != NVH_OK) return rc;
+    DecodeArgs a{q, q_token_stride, const_cast<void*>(k_cache), const_cast<void*>(v_cache), context_lens, block_tables,
+                 table_stride, batch, num_q_heads, num_kv_heads, head_dim, softmax_scale, out, num_splits, min_range_keys, ws,
+                 (hipStream_t)stream, DecodeItems{}, 0};
+    return launch_decode<false>("nvh_attn_decode_noalloc", a, FusedQkv{});
+}
+
 extern "C" int32_t nvh_attn_decode_items(const void* q, int64_t q_token_stride, const void* k_cache, const void* v_cache,
                                          const int32_t* context_lens, const int32_t* block_tables, int64_t table_stride,
                                          int64_t batch, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,

@@ -42,6 +42,10 @@ void nvh_set_error(const char* fmt, ...);
 int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits,
                                 const int32_t* ctx_lens, int hq, int min_range, const int32_t* seq_active, hipStream_t st);
 
+// Device address, on the current GPU, of the built-in partial-result array of nvh_attn_decode_noalloc (resolved on
+// first use; nvh_device_check resolves it ahead of time for callers that will run under graph capture).
+int32_t nvh_noalloc_scratch(float** out);
+
 static inline bool nvh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int64_t nvh_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

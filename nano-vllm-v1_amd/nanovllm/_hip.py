@@ -38,6 +38,8 @@ SIGNATURES = {
     "nvh_attn_varlen_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_varlen_suggest_splits": (i32, [i64, i64, i64, i64, i64]),
     "nvh_attn_decode": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, i32, vp, vp]),
+    "nvh_attn_decode_noalloc": (i32, [vp, i64, vp, vp, vp, vp, i64, i64, i64, i64, i64, f32, vp, i32, i32, vp]),
+    "nvh_attn_decode_noalloc_max_bytes": (i64, []),
     "nvh_comm_handle_bytes": (i32, []),
     "nvh_comm_create": (i32, [i32, i32, i64, vp]),
     "nvh_comm_get_handle": (i32, [vp, vp]),
