@@ -365,7 +365,9 @@ def main():
     if distributed:
         from nanovllm import comm as comm_mod
         out["tp_exchange"] = ("xgmi peer all-reduce (one kernel per projection, inside the native step and its hipGraph)"
-                              if runner.comm is not None else "torch.distributed (RCCL) between operator modules")
+                              if runner.comm is not None else
+                              (f"torch.distributed ({dist.get_backend()}) sums between the parts of the native step"
+                               if runner.native is not None else f"torch.distributed ({dist.get_backend()}) between operator modules"))
         out["comm_fallback_reason"] = comm_mod.fallback_reason      # None: the peer exchange passed its start-up check
         out["decode_graphs"] = bool(runner.graphs)
         out["native_executor"] = runner.native is not None

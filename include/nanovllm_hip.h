@@ -346,6 +346,19 @@ int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_toke
 /* hidden_out: bf16 [T, hidden] (the final-norm output). */
 int32_t nvh_qwen3_forward(const nvh_qwen3_model* model, const nvh_step* step, void* hidden_out,
                           void* workspace, int64_t workspace_bytes, nvh_stream_t stream);
+/* The same step for a tensor-parallel rank WITHOUT the built-in exchange (model->comm null): the sums over the ranks
+ * that the reference makes with dist.all_reduce (layers/linear.py:407-409, layers/embed_head.py:128-129) are made by the
+ * caller between the parts of the step, with any collective library on the same stream (RCCL through
+ * torch.distributed; capturable into a hipGraph with the launches).  Parts: 0 = embedding; 2l+1 = layer l from its
+ * input norm to the O projection; 2l+2 = layer l from the post-attention norm to the down projection; 2L+1 = final
+ * norm.  After part 0 the caller sums *embedding_sum ([T, hidden] bf16) in place over the ranks, after every other
+ * part but the last *projection_sum; nvh_qwen3_exchange_buffers names those two areas of `workspace`.  Several
+ * consecutive parts may be run by one call only when no sum falls between them (first_part == last_part otherwise). */
+int32_t nvh_qwen3_forward_parts(const nvh_qwen3_model* model, const nvh_step* step, void* hidden_out,
+                                void* workspace, int64_t workspace_bytes, int32_t first_part, int32_t last_part,
+                                nvh_stream_t stream);
+int32_t nvh_qwen3_exchange_buffers(const nvh_qwen3_model* model, int64_t num_tokens, int64_t batch, int32_t decode_splits,
+                                   void* workspace, void** embedding_sum, void** projection_sum);
 /* logits [num_rows, vocab_rows] bf16 = lm_head(hidden[last rows]); layers/embed_head.py:197-204.
  * rows_ws: bf16 [num_rows, hidden] scratch; cu_seqlens_q NULL -> hidden rows are used as they are.
  * With `comm` set: logits is [num_rows, world*vocab_rows] on rank 0 (:205-209) and unused (may be NULL) elsewhere. */

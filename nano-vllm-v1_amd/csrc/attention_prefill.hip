@@ -19,10 +19,15 @@
 // CU (<= 256 registers, 64 KB LDS), so one's softmax overlaps the other's MFMAs.  Nothing in the tile loop may
 // make the compiler wait for vmcnt(0) (that drains the prefetch): Q fragments are pinned in registers before
 // the loop, the transposing V reads are issued from inline asm, and the loop must stay free of register spills.
-// Long key ranges can be cut into `num_splits` ranges of whole tiles (gridDim.z = B * splits):
+// Key groups (KS): the waves of a workgroup can be KS copies of the (query head, row block) set; copy ks takes
+// key tiles ks, ks + KS, ... of the range, every step stages KS tiles and the copies merge their (max, sum, O)
+// through LDS at the end.  That puts twice the waves on a query block without partial results leaving the CU
+// (a 1024-token chunk of 16 heads is only 512 row blocks for 1024 SIMDs).
+// Long key ranges can also be cut into `num_splits` ranges of whole tiles (gridDim.z = B * splits):
 // each range leaves an unnormalised fp32 partial + (max, sum) and the decode path's combine
-// kernel merges them - this is what fills the chip when a chunk has few query blocks.
+// kernel merges them - this is what fills the chip when a chunk has few query blocks and many keys.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #define LOG2E 1.4426950408889634f
@@ -72,28 +77,31 @@ __device__ __forceinline__ int k_off(int row, int ch) {          // K tile
     return 256 * row + 16 * (ch ^ (row & 15));
 }
 
-template <int G, int RB, int STAGES, bool PAGED>
-__global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 && STAGES == 2 ? 2 : 1)) void attn_varlen_kernel(
+template <int G, int RB, int KS, int STAGES, bool PAGED>
+__global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS == 2 ? 2 : 1)) void attn_varlen_kernel(
     const bf16* __restrict__ q, int64_t q_stride, const bf16* __restrict__ kp, const bf16* __restrict__ vp,
     int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ tables, int64_t table_stride, int hkv, float scale_log2, bf16* __restrict__ out,
     int num_splits, int tiles_per_split, float* __restrict__ ws_acc, float* __restrict__ ws_ml) {
-    constexpr int NW = G * RB, BQ = 32 * RB;
-    constexpr int PIECES = 32;                                   // 1-KiB DMA pieces per K+V tile (4 keys each)
+    constexpr int NW1 = G * RB, NW = NW1 * KS, BQ = 32 * RB;     // NW1: waves of one key group
+    constexpr int PIECES = 32 * KS;                              // 1-KiB DMA pieces per step: KS x (K + V tile), 4 keys each
     constexpr int PW = (PIECES + NW - 1) / NW;                   // pieces per wave (uniform; extras duplicate)
     constexpr int STAGE = 2 * 64 * 256;                          // K tile + V tile
     static_assert(STAGES == 2 || STAGES == 4, "the stage offset is folded into LDS addresses as a bit field");
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x (K tile + V tile)
+    static_assert(KS == 1 || KS == 2, "one or two key groups");
+    static_assert(KS == 1 || 32 % NW == 0, "with key groups a wave's piece i must belong to the same tile for every wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x KS x (K tile + V tile)
 
     const int b = blockIdx.z / num_splits, split = blockIdx.z % num_splits, kvh = blockIdx.y;
     const int q_beg = cu_q[b], lq = cu_q[b + 1] - q_beg;
     const int k_beg = cu_k[b], lk = cu_k[b + 1] - k_beg;
-    const int qb0 = blockIdx.x * BQ;
+    const int qb0 = (gridDim.x - 1 - blockIdx.x) * BQ;           // last (longest, under the causal mask) query blocks first
     if (qb0 >= lq) return;
     const int hq = hkv * G;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave / RB, rb = wave % RB;
+    const int ks_id = wave / NW1, w1 = wave % NW1;               // key group, wave inside the group
+    const int g = w1 / RB, rb = w1 % RB;
     const int h = kvh * G + g;
     const int ql = lane & 31, hh = lane >> 5;
     const int shift = lk - lq;                                    // causal diagonal offset
@@ -131,25 +139,30 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 && STAGES == 2 ? 2 : 1)) 
         auto fetch_page = [&](int kt) {
             if constexpr (PAGED) page_ahead = table_row[min(kt >> 2, last_page)];
         };
-        auto stage = [&](int kt) {
-            LDS_AS char* base = (LDS_AS char*)smem + (kt & (STAGES - 1)) * STAGE;
-            int64_t tile_off;                                    // wave-uniform element offset of key kt*64
+        // Step `st` stages key tiles kt_beg + st*KS + j, j < KS, into slots (st % STAGES) * KS + j.  kt_beg is a multiple
+        // of KS and KS divides the 4 tiles of a page, so the tiles of a step share one page-table entry.  A tile past the
+        // last key of the sequence (odd tile count) re-reads the last valid tile: the DMA count per step stays uniform.
+        const int last_tile = max(lk - 1, 0) >> 6;
+        auto stage = [&](int st) {
+            const int kt0 = kt_beg + st * KS;
+            LDS_AS char* base = (LDS_AS char*)smem + (st & (STAGES - 1)) * (KS * STAGE);
+            int64_t page = 0;
             if constexpr (PAGED) {
-                const int64_t page = page_ahead;                 // fetch_page(kt) ran an iteration ago
-                fetch_page(kt + 1);
-                tile_off = (page * NVH_KV_PAGE + (kt & 3) * 64) * row_stride;
-            } else {
-                tile_off = (int64_t)(k_beg + kt * 64) * row_stride;
+                page = page_ahead;                               // fetch_page(kt0) ran an iteration ago
+                fetch_page(kt0 + KS);
             }
-            const bool full = kt * 64 + 63 < lk;
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 int p = wave + i * NW;
                 if (p >= PIECES) p -= PIECES;
-                const int isv = p >> 4, pv = p & 15;
+                const int kt = min(kt0 + (p >> 5), last_tile);   // (p >> 5: the same for every wave, see the static_assert)
+                int64_t tile_off;                                // wave-uniform element offset of key kt*64
+                if constexpr (PAGED) tile_off = (page * NVH_KV_PAGE + (kt & 3) * 64) * row_stride;
+                else tile_off = (int64_t)(k_beg + kt * 64) * row_stride;
+                const int isv = (p >> 4) & 1, pv = p & 15;
                 const bf16* sbase = (isv ? vp : kp) + tile_off + (int64_t)(4 * pv) * row_stride;
                 int off = dma_row + (isv ? (dma_cv ^ (8 * (pv & 3))) : (dma_ck ^ (32 * (pv & 3))));
-                if (!full) {
+                if (kt * 64 + 63 >= lk) {
                     // last, partly filled tile: keys past the end re-read the last valid key (they are masked anyway)
                     const int over = max(kt * 64 + 4 * pv + l4 - (lk - 1), 0);
                     off -= over * (int)row_stride;
@@ -169,9 +182,9 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 && STAGES == 2 ? 2 : 1)) 
         LDS_AS const char* lds = (LDS_AS const char*)smem;
 
         // One 64-key tile.  MASK: the tile crosses this wave's causal diagonal.
-        auto tile = [&](int kt, auto mask_tag) {
+        auto tile = [&](int kt, int slot, auto mask_tag) {
             constexpr bool MASK = decltype(mask_tag)::value;
-            const int soff = (kt & (STAGES - 1)) * STAGE;
+            const int soff = slot * STAGE;
             int kb[8], vb[4][2];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) kb[ks] = kb0 ^ ((32 * ks) ^ soff);
@@ -277,9 +290,10 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 && STAGES == 2 ? 2 : 1)) 
                 }
         };
 
-        constexpr int AHEAD = STAGES - 1;                       // tiles kept in flight
+        constexpr int AHEAD = STAGES - 1;                       // steps kept in flight
+        const int nsteps = (kt_end - kt_beg + KS - 1) / KS;
         fetch_page(kt_beg);
-        for (int t = 0; t < AHEAD && kt_beg + t < kt_end; ++t) stage(kt_beg + t);
+        for (int t = 0; t < AHEAD && t < nsteps; ++t) stage(t);
         // Q^T fragments: lane (q = ql, half hh) holds Q[q][16ks + 8hh .. +7].  Loaded AFTER the first DMAs were
         // issued (the latencies overlap) and pinned by an empty asm: from here on the compiler sees registers, not a
         // pending global load, so it does not drain the DMA queue (vmcnt(0)) at their first use in every tile.
@@ -290,28 +304,57 @@ __global__ __launch_bounds__(G * RB * 64, (G * RB <= 4 && STAGES == 2 ? 2 : 1)) 
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
         }
-        for (int kt = kt_beg; kt < kt_end; ++kt) {
-            // this wave's pieces of tile kt have landed (later tiles may still be in flight) ...
+        for (int st = 0; st < nsteps; ++st) {
+            // this wave's pieces of step st have landed (later steps may still be in flight) ...
             PROF_T(p0);
-            attn_wait_tiles<PW, AHEAD - 1>(min(AHEAD - 1, kt_end - 1 - kt));
+            attn_wait_tiles<PW, AHEAD - 1>(min(AHEAD - 1, nsteps - 1 - st));
             asm volatile("" ::: "memory");
             PROF_T(p1);
-            __builtin_amdgcn_s_barrier();                       // ... everyone's have, and tile kt-1 is consumed
+            __builtin_amdgcn_s_barrier();                       // ... everyone's have, and step st-1 is consumed
             asm volatile("" ::: "memory");
             PROF_T(p2);
-            if (kt + AHEAD < kt_end) stage(kt + AHEAD);         // into the slot of tile kt-1
+            if (st + AHEAD < nsteps) stage(st + AHEAD);         // into the slots of step st-1
             PROF_T(p3);
             PROF_ADD(0, p0, p1);
             PROF_ADD(1, p1, p2);
             PROF_ADD(2, p2, p3);
-            if (kt * 64 <= wave_last_key) {                     // else: tile entirely above this wave's diagonal
-                if (kt * 64 + 63 > wave_first_row + shift) tile(kt, std::true_type{});
-                else tile(kt, std::false_type{});
+            const int kt = kt_beg + st * KS + ks_id;            // this key group's tile of the step
+            if (kt < kt_end && kt * 64 <= wave_last_key) {      // else: no such tile, or entirely above this wave's diagonal
+                const int slot = (st & (STAGES - 1)) * KS + ks_id;
+                if (kt * 64 + 63 > wave_first_row + shift) tile(kt, slot, std::true_type{});
+                else tile(kt, slot, std::false_type{});
             }
             PROF_T(p4);
             PROF_ADD(3, p3, p4);
             PROF_ADD(4, p0, p0 + 1);
         }
+    }
+
+    if constexpr (KS > 1) {
+        // Merge the key groups: group 1 leaves (max, sum, O) of every lane in LDS (value-major, lane-minor: conflict
+        // free), group 0 folds it into its own state.  Both states are consistent (O, sum relative to their max).
+        __syncthreads();                                        // every wave is done with the staged tiles
+        float* mg = reinterpret_cast<float*>(smem) + (size_t)w1 * (66 * 64) + lane;
+        if (ks_id == 1) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mg[(dt * 16 + r) * 64] = o[dt][r];
+            mg[64 * 64] = m_run;
+            mg[65 * 64] = l_run;
+        }
+        __syncthreads();
+        if (ks_id == 1) return;
+        const float m_b = mg[64 * 64], l_b = mg[65 * 64];
+        const float m_new = fmaxf(m_run, m_b);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float fa = __builtin_amdgcn_exp2f(m_run - m_use), fb = __builtin_amdgcn_exp2f(m_b - m_use);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = o[dt][r] * fa + mg[(dt * 16 + r) * 64] * fb;
+        l_run = l_run * fa + l_b * fb;
+        m_run = m_new;
     }
 
     PROF_FLUSH;
@@ -365,35 +408,56 @@ struct VarlenArgs {
     float *ws_acc, *ws_ml;
 };
 
-template <int G, int RB, int STAGES>
+template <int G, int RB, int KS, int STAGES>
 void launch_varlen(bool paged, dim3 grid, hipStream_t st, const VarlenArgs& a) {
-    constexpr int smem = STAGES * 2 * 64 * 256;
+    constexpr int smem = STAGES * KS * 2 * 64 * 256;
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, STAGES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, STAGES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, KS, STAGES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)attn_varlen_kernel<G, RB, KS, STAGES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
     }
     if (paged)
-        attn_varlen_kernel<G, RB, STAGES, true><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
-                                                                                a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
+        attn_varlen_kernel<G, RB, KS, STAGES, true><<<grid, G * RB * KS * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
+                                                                                         a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
     else
-        attn_varlen_kernel<G, RB, STAGES, false><<<grid, G * RB * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
-                                                                                 a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
+        attn_varlen_kernel<G, RB, KS, STAGES, false><<<grid, G * RB * KS * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
+                                                                                          a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
 }
 
-// Query rows per workgroup: 4-5 waves (8 for G = 8), each 32 rows of one query head.
+// Query rows per workgroup: 4-5 waves per key group (8 for G = 8), each 32 rows of one query head.
 int rows_per_block(int g) { return g == 1 ? 128 : g == 2 ? 64 : 32; }
+// Key groups per workgroup (1 or 2) for a launch of `wgs` workgroups: two groups (8 waves, one workgroup per CU) while
+// the grid leaves CUs without a second workgroup anyway; four-wave workgroups, two per CU, beyond that.
+// Measured on 16 q / 8 kv heads (us per launch, one group vs two): Lq = Lk = 1024: 34.6 (29.9 with 4 key ranges and the
+// merge launch) vs 28.5; Lq 1024 / Lk 4096 in 2 ranges: 72.1 vs 58.1; 8 x 128 tokens: 10.0 vs 11.1 (nothing to share out);
+// 16 queries x 4 sequences over 4096 keys in many ranges: 26.4 vs 34.5.
+int key_groups(int g, int64_t wgs, int64_t total_q, int64_t max_seqlen_k) {
+    static const int force = getenv("NVH_ATTN_KS") ? atoi(getenv("NVH_ATTN_KS")) : 0;      // A/B switch for measurements
+    if (g != 1 && g != 2 && g != 4) return 1;
+    if (force == 1 || force == 2) return force;
+    return (wgs <= 384 && total_q > 256 && max_seqlen_k >= 512) ? 2 : 1;
+}
 }  // namespace
 
 extern "C" int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
                                                   int64_t max_seqlen_k) {
-    // Aim for ~512 workgroups (2 per CU); never less than 4 key tiles (256 keys) per range.
+    // Key ranges cost partial results (fp32 O per query row, head and range, written and read back), so a chunk with
+    // many query rows is only cut while every range keeps 1024 keys and the grid is short of one workgroup per CU
+    // (1024 queries of 16 heads over 4096 keys: 85.1 us uncut, 58.1 us in two ranges); a handful of queries over a long
+    // context (the tail of a prompt) is cut down to 256 keys per range.
     if (num_kv_heads <= 0 || num_q_heads % num_kv_heads) return 1;
     const int bq = rows_per_block((int)(num_q_heads / num_kv_heads));
     const int64_t blocks = (total_q / bq + batch) * num_kv_heads;
-    int64_t s = nvh_cdiv(512, blocks > 0 ? blocks : 1);
-    const int64_t cap = nvh_cdiv(max_seqlen_k, 64) / 4;
+    const int64_t tiles = nvh_cdiv(max_seqlen_k, 64);
+    int64_t s, cap;
+    if (total_q <= 256) {
+        s = nvh_cdiv(512, blocks > 0 ? blocks : 1);
+        cap = tiles / 4;
+    } else {
+        s = (256 + blocks / 2) / (blocks > 0 ? blocks : 1);     // nearest count to one workgroup per CU
+        cap = tiles / 16;                                      // at least 1024 keys per range
+    }
     if (s > cap) s = cap;
     if (s > 32) s = 32;
     return (int32_t)(s < 1 ? 1 : s);
@@ -425,20 +489,23 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
     float* ws_acc = (float*)workspace;
     float* ws_ml = ws_acc ? ws_acc + total_q * num_q_heads * num_splits * 128 : nullptr;
     const int tiles = (int)nvh_cdiv(max_seqlen_k > 0 ? max_seqlen_k : 1, 64);
+    const int64_t wgs = nvh_cdiv(max_seqlen_q, rows_per_block(g)) * num_kv_heads * batch * num_splits;
+    const int ks = key_groups(g, wgs, total_q, max_seqlen_k);
+    // whole steps of `ks` tiles per key range (a step's tiles then share one page of the block table)
     VarlenArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, q_token_stride, kv_token_stride, cu_seqlens_q, cu_seqlens_k,
                  block_tables, table_stride, (int)num_kv_heads, softmax_scale * LOG2E, (bf16*)out, num_splits,
-                 (int)nvh_cdiv(tiles, num_splits), ws_acc, ws_ml};
-#define LAUNCH_VL(GG, RBB)                                                                                                  \
+                 (int)(nvh_cdiv(nvh_cdiv(tiles, num_splits), ks) * ks), ws_acc, ws_ml};
+#define LAUNCH_VL(GG, RBB, KSS)                                                                                             \
     do {                                                                                                                    \
         dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));      \
-        launch_varlen<GG, RBB, 2>(paged, grid, st, a);                                                                      \
+        launch_varlen<GG, RBB, KSS, 2>(paged, grid, st, a);                                                                 \
     } while (0)
     switch (g) {
-        case 1: LAUNCH_VL(1, 4); break;
-        case 2: LAUNCH_VL(2, 2); break;
-        case 4: LAUNCH_VL(4, 1); break;
-        case 5: LAUNCH_VL(5, 1); break;
-        case 8: LAUNCH_VL(8, 1); break;
+        case 1: if (ks == 2) LAUNCH_VL(1, 4, 2); else LAUNCH_VL(1, 4, 1); break;
+        case 2: if (ks == 2) LAUNCH_VL(2, 2, 2); else LAUNCH_VL(2, 2, 1); break;   // 32- and 128-row blocks measured slower
+        case 4: if (ks == 2) LAUNCH_VL(4, 1, 2); else LAUNCH_VL(4, 1, 1); break;
+        case 5: LAUNCH_VL(5, 1, 1); break;
+        case 8: LAUNCH_VL(8, 1, 1); break;
         default:
             nvh_set_error("nvh_attn_varlen: group size Hq/Hkv = %d unsupported (1,2,4,5,8)", g);
             return NVH_ENOSYS;

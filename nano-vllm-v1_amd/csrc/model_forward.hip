@@ -80,8 +80,15 @@ static int32_t decode_attention(const nvh_qwen3_model* md, const nvh_step* st, i
         if (rc__ != NVH_OK) return rc__; \
     } while (0)
 
-extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* st, void* hidden_out, void* workspace,
-                                     int64_t workspace_bytes, nvh_stream_t stream) {
+// The step is a chain of parts separated by the sums over the tensor-parallel ranks:
+//   part 0            embedding                                        (its sum: the residual stream)
+//   part 2l+1         layer l: input norm .. O projection             (its sum: the projection output)
+//   part 2l+2         layer l: post-attention norm .. down projection (its sum: the projection output)
+//   part 2L+1         final norm
+// `external`: the caller sums between the parts (a collective library on the same stream); no split-K slab hand-off
+// then, because partial sums of different ranks meet in bf16.
+static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void* hidden_out, void* workspace,
+                            int64_t workspace_bytes, nvh_stream_t stream, int first_part, int last_part, bool external) {
     NVH_REQUIRE(md && st && hidden_out, NVH_EINVAL, "nvh_qwen3_forward: null pointer");
     NVH_REQUIRE(md->head_dim == 128, NVH_ENOSYS, "nvh_qwen3_forward: head_dim %d unsupported", md->head_dim);
     const int64_t t = st->num_tokens, b = st->batch;
@@ -109,7 +116,9 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
     const int64_t qsz = hq * d, kvsz = hkv * d, qkv_n = qsz + 2 * kvsz;
     const float scale = 1.0f / sqrtf((float)d);
     // partial sums of different ranks meet in bf16: no split-K slab hand-off under tensor parallelism
-    const int32_t so = md->comm ? 1 : split_for(t, h, qsz), sd = md->comm ? 1 : split_for(t, h, md->inter);
+    const bool sharded = md->comm || external;
+    const int32_t so = sharded ? 1 : split_for(t, h, qsz), sd = sharded ? 1 : split_for(t, h, md->inter);
+    auto runs = [&](int part) { return part >= first_part && part <= last_part; };
     const int32_t sq = split_for_qkv(t, qkv_n, h);
 
     nvh_comm* comm = md->comm;
@@ -122,12 +131,17 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
     // all-reduce (less xGMI traffic) followed by the norm
     static const bool no_fused = getenv("NVH_NO_FUSED_EXCHANGE") != nullptr;
     const bool fused_exchange = comm && !no_fused && t * h * 2 <= (int64_t)(1 << 20);
-    FWD(nvh_embedding(st->input_ids, md->embed, w.residual, t, h, md->vocab_start, md->vocab_rows, stream));
-    if (comm) FWD(nvh_allreduce_bf16(comm, w.residual, w.residual, t * h, stream));
-    bool pending_slabs = false;         // the previous projection left split-K slabs in w.slabs
-    int32_t pending_count = 0;
-    bf16* pending_y = nullptr;          // or a reduced bf16 result
+    if (runs(0)) {
+        FWD(nvh_embedding(st->input_ids, md->embed, w.residual, t, h, md->vocab_start, md->vocab_rows, stream));
+        if (comm) FWD(nvh_allreduce_bf16(comm, w.residual, w.residual, t * h, stream));
+    }
+    // what the down projection of the previous layer left behind: split-K slabs in w.slabs, or a bf16 result in w.y
+    // (summed over the ranks already, unless the fused exchange takes the partial sums straight from proj_out)
+    const bool pending_slabs = sd > 1;
+    const int32_t pending_count = sd > 1 ? sd : 0;
+    bf16* const pending_y = sd > 1 ? nullptr : w.y;
     for (int l = 0; l < md->layers; ++l) {
+      if (runs(2 * l + 1)) {
         // ---- input norm: layer 0 normalises the embedding; later layers add the MLP output first
         if (l == 0) {
             FWD(nvh_rmsnorm(w.residual, h, md->input_norm[l], w.x, h, t, h, md->eps, stream));
@@ -182,12 +196,15 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
                                     nullptr, 0, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
             }
         }
-        // ---- O projection -> add + norm
+        // ---- O projection
+        if (so > 1) FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, nullptr, h, t, h, qsz, so, w.slabs, stream));
+        else FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, proj_out, h, t, h, qsz, 1, nullptr, stream));
+      }
+      if (runs(2 * l + 2)) {
+        // ---- add + norm
         if (so > 1) {
-            FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, nullptr, h, t, h, qsz, so, w.slabs, stream));
             FWD(nvh_add_rmsnorm(nullptr, w.residual, md->post_norm[l], w.x, t, h, md->eps, w.slabs, so, stream));
         } else {
-            FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, proj_out, h, t, h, qsz, 1, nullptr, stream));
             if (comm && fused_exchange) {
                 FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->post_norm[l], w.x, t, h, md->eps, stream));
             } else {
@@ -204,23 +221,42 @@ extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* 
         }
         if (sd > 1) {
             FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, nullptr, h, t, h, md->inter, sd, w.slabs, stream));
-            pending_slabs = true;
-            pending_count = sd;
-            pending_y = nullptr;
         } else {
             FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, proj_out, h, t, h, md->inter, 1, nullptr, stream));
             if (comm && !fused_exchange) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
-            pending_slabs = false;
-            pending_count = 0;
-            pending_y = w.y;                 // (with the fused exchange the partial sums stay in proj_out)
+        }
+      }
+    }
+    if (runs(2 * md->layers + 1)) {
+        if (comm && fused_exchange) {
+            FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->final_norm, hidden_out, t, h, md->eps, stream));
+        } else {
+            FWD(nvh_add_rmsnorm(pending_y, w.residual, md->final_norm, hidden_out, t, h, md->eps,
+                                pending_slabs ? w.slabs : nullptr, pending_count, stream));
         }
     }
-    if (comm && fused_exchange) {
-        FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->final_norm, hidden_out, t, h, md->eps, stream));
-    } else {
-        FWD(nvh_add_rmsnorm(pending_y, w.residual, md->final_norm, hidden_out, t, h, md->eps,
-                            pending_slabs ? w.slabs : nullptr, pending_count, stream));
-    }
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_qwen3_forward(const nvh_qwen3_model* md, const nvh_step* st, void* hidden_out, void* workspace,
+                                     int64_t workspace_bytes, nvh_stream_t stream) {
+    return forward_impl(md, st, hidden_out, workspace, workspace_bytes, stream, 0, md ? 2 * md->layers + 1 : 0, false);
+}
+
+extern "C" int32_t nvh_qwen3_forward_parts(const nvh_qwen3_model* md, const nvh_step* st, void* hidden_out, void* workspace,
+                                           int64_t workspace_bytes, int32_t first_part, int32_t last_part, nvh_stream_t stream) {
+    NVH_REQUIRE(md && !md->comm, NVH_EINVAL, "nvh_qwen3_forward_parts: for ranks WITHOUT the built-in exchange (model->comm must be null)");
+    NVH_REQUIRE(first_part >= 0 && first_part <= last_part && last_part <= 2 * md->layers + 1, NVH_EINVAL,
+                "nvh_qwen3_forward_parts: parts %d..%d outside 0..%d", first_part, last_part, 2 * md->layers + 1);
+    return forward_impl(md, st, hidden_out, workspace, workspace_bytes, stream, first_part, last_part, true);
+}
+
+extern "C" int32_t nvh_qwen3_exchange_buffers(const nvh_qwen3_model* md, int64_t num_tokens, int64_t batch, int32_t decode_splits,
+                                              void* workspace, void** embedding_sum, void** projection_sum) {
+    NVH_REQUIRE(md && workspace && embedding_sum && projection_sum, NVH_EINVAL, "nvh_qwen3_exchange_buffers: null pointer");
+    const Workspace w = carve(md, num_tokens, batch, decode_splits < 1 ? 1 : decode_splits, kMaxVarlenSplits, (char*)workspace);
+    *embedding_sum = w.residual;
+    *projection_sum = w.y;
     return NVH_OK;
 }
 

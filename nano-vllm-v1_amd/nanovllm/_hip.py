@@ -64,6 +64,8 @@ SIGNATURES = {
     # struct pointers (nvh_qwen3_model*, nvh_step*) travel as void*; layouts are in nanovllm/native.py
     "nvh_qwen3_workspace_bytes": (i64, [vp, i64, i64, i32]),
     "nvh_qwen3_forward": (i32, [vp, vp, vp, vp, i64, vp]),
+    "nvh_qwen3_forward_parts": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+    "nvh_qwen3_exchange_buffers": (i32, [vp, i64, i64, i32, vp, vp, vp]),
     "nvh_qwen3_logits": (i32, [vp, vp, vp, vp, i64, vp, vp, vp]),
 }
 

@@ -167,10 +167,14 @@ class ModelRunner:
             vocab_shard = hf.vocab_size // self.world_size
             nbytes = 2 * max(config.max_num_batched_tokens * hf.hidden_size, config.max_num_seqs * vocab_shard)
             self.comm = comm.install(rank, self.world_size, nbytes)
-            if self.comm is None and not self.enforce_eager:
-                # operator modules + torch.distributed collectives: keep them out of graph capture
-                print(f"[nanovllm] rank {rank}: no peer exchange, running tensor parallel eagerly", file=sys.stderr)
-                self.enforce_eager = True
+            if self.comm is None:
+                # No peer exchange: the native step still issues every launch, the sums between its parts go through
+                # torch.distributed.  RCCL collectives capture into the decode hipGraphs with the launches; any other
+                # backend (gloo rehearsals stage through the host) cannot be captured and runs eagerly.
+                print(f"[nanovllm] rank {rank}: no peer exchange ({comm.fallback_reason}); sums over the ranks go through "
+                      f"torch.distributed ({dist.get_backend()})", file=sys.stderr)
+                if dist.get_backend() != "nccl":
+                    self.enforce_eager = True
 
         dtype = model_dtype(hf)
         if dtype != torch.bfloat16:
@@ -190,15 +194,23 @@ class ModelRunner:
             # one native call per step (per rank; ranks meet through the xGMI exchange); the operator modules,
             # with torch.distributed collectives between them when the exchange is unavailable, otherwise.
             # NANOVLLM_NATIVE=0 forces the module path (parity tests use it).
-            use_native = (self.world_size == 1 or self.comm is not None) and os.environ.get("NANOVLLM_NATIVE", "1") != "0" \
-                and not getattr(hf, "attention_bias", True)
-            self.native = NativeQwen3(self.model, comm=self.comm) if use_native else None
+            use_native = os.environ.get("NANOVLLM_NATIVE", "1") != "0" and not getattr(hf, "attention_bias", True)
+            external_sum = comm.all_reduce if (self.world_size > 1 and self.comm is None) else None
+            self.native = NativeQwen3(self.model, comm=self.comm, reduce_fn=external_sum) if use_native else None
             self.warmup_model()
             self.allocate_kv_cache()
             if self.native is not None:
                 self.native.rebuild()
             if not self.enforce_eager:
-                self.capture_graphs()
+                try:
+                    self.capture_graphs()
+                except Exception as e:                              # noqa: BLE001
+                    if self.world_size == 1 or self.comm is not None:
+                        raise
+                    # a collective that would not capture: keep the native step, run it eagerly
+                    print(f"[nanovllm] rank {rank}: decode graphs unavailable with torch.distributed sums ({e}); eager steps",
+                          file=sys.stderr)
+                    self.graphs, self.graph_bs, self.enforce_eager = {}, [], True
         finally:
             torch.set_default_device("cpu")
             torch.set_default_dtype(prev_dtype)

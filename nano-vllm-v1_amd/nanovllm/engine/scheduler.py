@@ -26,6 +26,7 @@ class Scheduler:
         self.block_manager = BlockManager(config.num_kvcache_blocks, config.kvcache_block_size)
         self.waiting: deque[Sequence] = deque()
         self.running: deque[Sequence] = deque()
+        self.num_preemptions = 0            # bookkeeping for the serving harness; scheduling never reads it
 
     def is_finished(self) -> bool:
         return not self.waiting and not self.running
@@ -108,6 +109,7 @@ class Scheduler:
         seq.status = SequenceStatus.WAITING
         self.block_manager.deallocate(seq)
         self.waiting.appendleft(seq)
+        self.num_preemptions += 1
 
     def postprocess(self, seqs: list[Sequence], token_ids: list[int], seq_need_compute_logits) -> None:
         need = [int(i) for i in seq_need_compute_logits]

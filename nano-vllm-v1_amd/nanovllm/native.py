@@ -39,11 +39,22 @@ def _ptr(t):
     return 0 if t is None or t.numel() == 0 else t.data_ptr()
 
 
+def _raw_bf16(ptr: int, numel: int) -> torch.Tensor:
+    """bf16 view of device memory owned by someone else (an area of the step workspace)."""
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (numel,), "typestr": "<u2", "data": (ptr, False), "version": 3}
+    return torch.as_tensor(_Raw(), device="cuda").view(torch.bfloat16)
+
+
 class NativeQwen3:
-    def __init__(self, model, fuse_swiglu: bool = True, comm=None):
+    def __init__(self, model, fuse_swiglu: bool = True, comm=None, reduce_fn=None):
+        """`comm`: the peer exchange of a tensor-parallel rank (sums happen inside the native step).  `reduce_fn`: for a
+        tensor-parallel rank WITHOUT that exchange - an in-place sum over the ranks (torch.distributed / RCCL) that the
+        step calls between its parts; the launches still come from native code and still capture into a hipGraph."""
         self.lib = _hip.lib()
         self.model = model
         self.comm = comm
+        self.reduce_fn = reduce_fn if comm is None else None
         self.fuse_swiglu = fuse_swiglu
         self.rebuild()
 
@@ -120,14 +131,38 @@ class NativeQwen3:
         nbytes = self.lib.nvh_qwen3_workspace_bytes(C.byref(self.desc), t, batch, st.decode_splits)
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         out = torch.empty(t, self.desc.hidden, dtype=torch.bfloat16, device=self.device)
-        _hip.check(self.lib.nvh_qwen3_forward(C.byref(self.desc), C.byref(st), out.data_ptr(), ws.data_ptr(), nbytes,
-                                              torch.cuda.current_stream().cuda_stream), "nvh_qwen3_forward")
+        stream = torch.cuda.current_stream().cuda_stream
+        if self.reduce_fn is None:
+            _hip.check(self.lib.nvh_qwen3_forward(C.byref(self.desc), C.byref(st), out.data_ptr(), ws.data_ptr(), nbytes, stream),
+                       "nvh_qwen3_forward")
+            return out
+        # one native call per part of the step, the caller's sum over the ranks between them
+        emb, proj = vp(), vp()
+        _hip.check(self.lib.nvh_qwen3_exchange_buffers(C.byref(self.desc), t, batch, st.decode_splits, ws.data_ptr(),
+                                                       C.byref(emb), C.byref(proj)), "nvh_qwen3_exchange_buffers")
+        n = t * self.desc.hidden
+        sums = (_raw_bf16(emb.value, n), _raw_bf16(proj.value, n))
+        last = 2 * self.desc.layers + 1
+        for part in range(last + 1):
+            _hip.check(self.lib.nvh_qwen3_forward_parts(C.byref(self.desc), C.byref(st), out.data_ptr(), ws.data_ptr(), nbytes,
+                                                        part, part, stream), "nvh_qwen3_forward_parts")
+            if part < last:
+                self.reduce_fn(sums[0] if part == 0 else sums[1])
         return out
 
     def logits(self, hidden, cu_seqlens_q=None, need=None, num_rows=None):
         """lm_head over the last scheduled row of the selected sequences (cu_seqlens_q None: `hidden`
         rows are used directly)."""
         n = hidden.shape[0] if cu_seqlens_q is None else num_rows
+        if self.reduce_fn is not None:
+            # this rank's vocabulary shard, then the gather to rank 0 through torch.distributed (layers/embed_head.py:205-209)
+            from . import comm as comm_mod
+            shard = torch.empty(n, self.desc.vocab_rows, dtype=torch.bfloat16, device=self.device)
+            rows = torch.empty(n, self.desc.hidden, dtype=torch.bfloat16, device=self.device) if cu_seqlens_q is not None else None
+            _hip.check(self.lib.nvh_qwen3_logits(C.byref(self.desc), hidden.data_ptr(), _ptr(cu_seqlens_q), _ptr(need), n,
+                                                 _ptr(rows), shard.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "nvh_qwen3_logits")
+            return comm_mod.gather_cols(shard, 0)
         if self.comm is None:
             out = torch.empty(n, self.desc.vocab_rows, dtype=torch.bfloat16, device=self.device)
         elif self.comm.rank == 0:

@@ -133,8 +133,10 @@ def main(argv=None):
         llm.generate(*batch(args.warmup_requests), use_tqdm=False)
     prompts, sps = batch(args.num_requests)
     arrivals = np.cumsum(np.random.exponential(1.0 / args.request_rate, args.num_requests))
+    before = llm.scheduler.num_preemptions
     clocks, wall = serve(llm, prompts, sps, arrivals)
     r = summarize(clocks, wall)
+    r["preemptions"] = llm.scheduler.num_preemptions - before
     print("--- Benchmark Results ---")
     print(f"Total time: {r['total_time_s']:.2f}s")
     print(f"Requests sent: {r['requests']}")

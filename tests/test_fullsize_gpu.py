@@ -172,3 +172,57 @@ def test_lm_head_gemm_at_full_vocabulary_against_fp32():
     ref = x.float() @ w.float().t()
     err = (y - ref).abs()
     assert bool((err <= 1e-2 + 8e-3 * ref.abs()).all()), f"max err {float(err.max()):.4g}"     # one bf16 rounding of the fp32 sum
+
+
+@pytest.mark.parametrize("tokens", [1024, 800])
+def test_fused_qkv_epilogue_route_equals_two_launch_route(eager, tokens):
+    """A chunk of 769..1024 tokens takes the QKV projection whose epilogue applies the q/k RMSNorm + RoPE and stores K/V
+    (one launch inside the native step); smaller chunks project first and run the epilogue kernel afterwards.  The K/V
+    rows of the FIRST layer depend on nothing but the embedding, the norm, that projection and its epilogue, row by row,
+    so both routes must leave the same bits in the cache; the logits after the last chunk agree to rounding (attention
+    sums over the chunks in a different order)."""
+    p = prompts([tokens], 40 + tokens)[0]
+    half = tokens // 2
+    one_table, two_table = [28, 29, 30, 31], [32, 33, 34, 35]
+    a, _, _ = eager.forward_logits([seq(p, 0, tokens, one_table)])          # one chunk: fused epilogue
+    s = seq(p, 0, 0, two_table)
+    b = None
+    for n in (half, tokens - half):                                         # 512 / 400 rows: two launches
+        s.num_new_tokens = n
+        b, _, _ = eager.forward_logits([s])
+        s.num_cached_tokens += n
+    kv = eager.kv_cache
+    pages = (tokens + 255) // 256
+    for which in (0, 1):
+        fused = kv[which, 0, one_table[0]:one_table[0] + pages].reshape(-1, kv.shape[-2], kv.shape[-1])[:tokens]
+        split = kv[which, 0, two_table[0]:two_table[0] + pages].reshape(-1, kv.shape[-2], kv.shape[-1])[:tokens]
+        assert torch.equal(fused, split), f"layer-0 {'KV'[which]} rows differ between the routes"
+    close(b, a)
+    greedy_agrees(b, a)
+
+
+def test_kv_pool_sized_from_free_memory():
+    """num_kvcache_blocks <= 0 (the reference's only mode, engine/model_runner.py:319-375): the pool takes what
+    gpu_memory_utilization leaves after the weights and the peak activations of the warm-up step, and the count is
+    written back into the config for the scheduler.  The utilisation is set so the pool stays near 3 GB."""
+    from nanovllm.config import Config
+    from nanovllm.engine.model_runner import ModelRunner
+    torch.cuda.empty_cache()                                     # as the runner's warm-up does: only live tensors count
+    free, total = torch.cuda.mem_get_info()
+    util = (total - free + (5 << 30)) / total                    # current use + weights/activations (~2 GB) + ~3 GB of pool
+    cfg = Config(MODEL, max_num_batched_tokens=1024, max_num_seqs=8, max_model_len=2048, enforce_eager=True,
+                 num_kvcache_blocks=-1, gpu_memory_utilization=util, chunked_prefill=True)
+    runner = ModelRunner(cfg, 0, [])
+    try:
+        n = cfg.num_kvcache_blocks
+        assert n > 0 and runner.kv_cache.shape[2] == n
+        block = runner.kv_block_bytes()
+        assert block == 2 * 28 * 256 * 8 * 128 * 2                # 28 MiB per page over all layers
+        assert (1 << 30) < n * block < (5 << 30), f"{n} pages"
+        free_after, _ = torch.cuda.mem_get_info()
+        assert total - free_after <= total * util + (256 << 20), "the pool overshoots gpu_memory_utilization"
+        p = prompts([300], 9)[0]
+        logits, _, need = runner.forward_logits([seq(p, 0, 300, [n - 2, n - 1])])      # the last pages are usable
+        assert need.tolist() == [0] and bool(torch.isfinite(logits.float()).all())
+    finally:
+        runner.exit()

@@ -391,3 +391,25 @@ def test_uneven_contexts_decode_takes_the_work_list(monkeypatch):
             runner.exit()
     for a, b in zip(outs["eager"], outs["graph"]):
         assert torch.equal(a, b)
+
+
+def test_graph_is_skipped_when_a_one_token_chunk_needs_no_logits(graphed):
+    """Chunked prefill left with a budget of exactly one token (max_num_batched_tokens = running sequences + 1): every
+    sequence of the step brings one token, but the chunk does not finish its prompt and must get no logits row.  The
+    captured decode graph computes a row for every sequence, so such a step has to run eagerly; logits rows and the need
+    list must line up (Scheduler.postprocess zips them) and match the oracle."""
+    runner, oracle = graphed
+    g = torch.Generator().manual_seed(123)
+    a, b = (torch.randint(0, 1024, (n,), generator=g).tolist() for n in (30, 41))
+    long = torch.randint(0, 1024, (20,), generator=g).tolist()
+    for toks, tb in ((a[:-1], [0]), (b[:-1], [1]), (long[:5], [2])):
+        runner.forward_logits([seq(toks, 0, len(toks), tb)])
+        oracle.run([M.SeqState(list(toks), 0, len(toks), list(tb))])
+    batch = [seq(a, 29, 1, [0]), seq(b, 40, 1, [1]), seq(long, 5, 1, [2])]
+    logits, _, need = runner.forward_logits(batch)
+    assert need.tolist() == [0, 1] and logits.shape[0] == 2
+    ref, _ = oracle.run([M.SeqState(list(a), 29, 1, [0]), M.SeqState(list(b), 40, 1, [1]), M.SeqState(list(long), 5, 1, [2])])
+    close(logits, ref)
+    assert torch.equal(logits.float().cpu().argmax(-1), ref.float().argmax(-1))
+    toks, need2 = runner.run(batch)
+    assert len(toks) == need2.numel() == 2
