@@ -196,8 +196,11 @@ def time_decode(driver, seqs, steps, warmup, distributed):
 
 
 def kernel_roofline(runner, seqs, iters):
-    """Average duration of the dominant decode kernel (paged attention over the KV pool), timed with
-    HIP events on the launch stream; every launch reads a different layer's cache, as a real step does."""
+    """Average duration of the dominant decode kernel exactly as the step runs it: attn_decode_kernel<G, fused> -
+    q/k norm + RoPE + KV store of the new token + paged attention straight from the raw qkv rows
+    (nvh_attn_decode_fused_qkv, the instance the captured graph replays) - timed with HIP events on the launch
+    stream; every launch reads a different layer's cache, as a real step does.  Run after everything else: the
+    launches store synthetic K/V rows for the newest token of every sequence."""
     from nanovllm import ops
     from nanovllm.engine.model_runner import flatten_batch
     hf = runner.config.hf_config
@@ -205,10 +208,13 @@ def kernel_roofline(runner, seqs, iters):
     fb = flatten_batch(seqs)
     ctx = torch.from_numpy(fb["context_lens"]).cuda()
     tables = torch.from_numpy(fb["block_tables"]).cuda()
+    positions = (ctx.long() - 1).clamp(min=0)
     b = len(seqs)
     hq, hkv, d = hf.num_attention_heads // tp, hf.num_key_value_heads // tp, hf.head_dim
-    q = torch.randn(b, hq, d, device="cuda").to(torch.bfloat16)
-    splits = ops.suggest_decode_splits(b, hkv, runner.config.max_model_len)
+    qkv = torch.randn(b, (hq + 2 * hkv) * d, device="cuda").to(torch.bfloat16)
+    attn0 = runner.model.model.layers[0].self_attn
+    cos_sin = attn0.rotary_emb.table2d()
+    splits = runner.decode_splits(b)
     layers = hf.num_hidden_layers
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(layers)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(layers)]
@@ -216,7 +222,8 @@ def kernel_roofline(runner, seqs, iters):
     for it in range(iters + 1):
         for li in range(layers):
             starts[li].record()
-            ops.attn_decode(q, runner.kv_cache[0, li], runner.kv_cache[1, li], ctx, tables, d ** -0.5, num_splits=splits)
+            ops.attn_decode_fused_qkv(qkv, hq, hkv, attn0.q_norm.weight, attn0.k_norm.weight, attn0.q_norm.eps, positions, cos_sin,
+                                      runner.kv_cache[0, li], runner.kv_cache[1, li], ctx, tables, d ** -0.5, num_splits=splits)
             ends[li].record()
         torch.cuda.synchronize()
         if it:                              # first sweep is warm-up
@@ -234,44 +241,130 @@ def kernel_roofline(runner, seqs, iters):
         ratio = rec["traffic_bytes_per_launch"] / rec["algorithmic_bytes_per_launch_at_ctx1027"]
         traffic = int(bytes_per_launch * ratio)
         traffic_note = f"profiles/{pmc.name}: measured/algorithmic = {ratio:.4f}"
-    return dict(bound="hbm", kernel="attn_decode_kernel" + ("+combine" if splits > 1 else ""), achieved=round(achieved, 1),
+    g = hq // hkv
+    return dict(bound="hbm", kernel=f"attn_decode_kernel<{g}, true>" + (" + merge" if splits > 1 else ""),
+                entry_point="nvh_attn_decode_fused_qkv (the launch the decode graph replays)", achieved=round(achieved, 1),
                 peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 traffic_source=traffic_note, avg_launch_us=round(avg_ms * 1e3, 2), bytes_per_launch=bytes_per_launch,
                 launches_timed=n)
 
 
-def cpu_baseline(hf, budget_s=12.0):
-    """The CPU oracle (oracle/ref_model.py, torch-CPU eager) on the same architecture and weight
-    recipe, timed on this host: decode, B=8 sequences at context 128."""
+def prefill_kernel_roofline(hf, tokens=1024, iters=3):
+    """The kernels of one 1024-token prefill chunk (no cached prefix), each timed with HIP events on the launch stream
+    over rotating weight copies (a layer's weights are cold when its kernels run): flops, time and fraction of the bf16
+    MFMA peak per kernel, and which of them takes the largest share of the chunk."""
+    from nanovllm import ops
+    h, d = hf.hidden_size, hf.head_dim
+    hq, hkv, inter = hf.num_attention_heads, hf.num_key_value_heads, hf.intermediate_size
+    copies = 12
+    bf = torch.bfloat16
+
+    def w(n, k):
+        return [(torch.randn(n, k, device="cuda") * 0.02).to(bf) for _ in range(copies)]
+
+    x = torch.randn(tokens, h, device="cuda").to(bf)
+    xa = torch.randn(tokens, hq * d, device="cuda").to(bf)
+    xi = torch.randn(tokens, inter, device="cuda").to(bf)
+    wq, wo, wd = w((hq + 2 * hkv) * d, h), w(h, hq * d), w(h, inter)
+    wg = [ops.interleave_gate_up(t) for t in w(2 * inter, h)]
+    q = torch.randn(tokens, hq, d, device="cuda").to(bf)
+    kv = [torch.randn(2, tokens, hkv, d, device="cuda").to(bf) for _ in range(copies)]
+    cu = torch.tensor([0, tokens], dtype=torch.int32, device="cuda")
+    cases = {
+        "qkv_proj gemm": (lambda i: ops.linear(x, wq[i]), 2 * tokens * h * (hq + 2 * hkv) * d),
+        "o_proj gemm": (lambda i: ops.linear(xa, wo[i]), 2 * tokens * h * hq * d),
+        "gate_up gemm + SwiGLU": (lambda i: ops.linear_swiglu(x, wg[i]), 2 * tokens * h * 2 * inter),
+        "down_proj gemm": (lambda i: ops.linear(xi, wd[i]), 2 * tokens * h * inter),
+        "attn_varlen_kernel": (lambda i: ops.attn_varlen(q, kv[i][0], kv[i][1], cu, cu, tokens, d ** -0.5), 4 * hq * d * tokens * (tokens + 1) // 2),
+    }
+    out, total_us = {}, 0.0
+    for name, (fn, flops) in cases.items():
+        # `copies` launches captured into one hipGraph (no host launch cost between them), replayed between two events
+        for i in range(copies):
+            fn(i)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(copies):
+                fn(i)
+        graph.replay()
+        best = 1e30
+        for _ in range(iters):
+            s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            graph.replay()
+            e0.record()
+            torch.cuda.synchronize()
+            best = min(best, s0.elapsed_time(e0) * 1e3 / copies)
+        us = best
+        total_us += us
+        out[name] = dict(us=round(us, 2), tflops=round(flops / us / 1e6, 1), frac=round(flops / us / 1e6 / MFMA_PEAK_TFLOPS, 4))
+    dominant = max(out, key=lambda k: out[k]["us"])
+    pmc = ROOT / "profiles" / "r02_prefill_mfma_pmc.txt"
+    return dict(bound="mfma", kernel=dominant, achieved=out[dominant]["tflops"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                frac=out[dominant]["frac"], per_kernel=out, per_layer_us=round(total_us, 1),
+                mfma_busy_source=(f"profiles/{pmc.name}" if pmc.exists() else None),
+                note="HIP-event time per launch over 12 back-to-back launches replayed from a hipGraph (rotating cold weights); one layer = these five + two add/RMSNorm launches")
+
+
+def cpu_baseline(hf):
+    """The CPU oracle (oracle/ref_model.py, torch-CPU eager) on the same architecture and weight recipe, driven through
+    the scheduler and page manager like the engine drives the GPU runner: decode at B = 1 and B = 8 (128-token contexts)
+    and one 1024-token prefill chunk; wall clock, median of 5 after one warm-up each."""
+    from types import SimpleNamespace
     from oracle import ref_model as M
+    from nanovllm.engine.scheduler import Scheduler
+    from nanovllm.engine.sequence import Sequence
+    from nanovllm.sampling_params import SamplingParams
     torch.manual_seed(0)
     shape = M.ModelShape(hidden_size=hf.hidden_size, num_hidden_layers=hf.num_hidden_layers,
                          num_attention_heads=hf.num_attention_heads, num_key_value_heads=hf.num_key_value_heads,
                          head_dim=hf.head_dim, intermediate_size=hf.intermediate_size, vocab_size=hf.vocab_size,
                          max_position_embeddings=4096, tie_word_embeddings=True)
     w = M.random_weights(shape, seed=0)
-    b, ctx = 8, 128
-    runner = M.RefRunner(shape, w, num_blocks=b)
+    pages = 16
+    runner = M.RefRunner(shape, w, num_blocks=pages)
     g = torch.Generator().manual_seed(0)
-    seqs = [M.SeqState(torch.randint(0, 10000, (ctx,), generator=g).tolist(), 0, ctx, [i]) for i in range(b)]
+
+    def engine():
+        return Scheduler(SimpleNamespace(chunked_prefill=True, max_model_len=4096, max_num_seqs=8, max_num_batched_tokens=1024,
+                                         eos=-1, num_kvcache_blocks=pages, kvcache_block_size=PAGE))
+
+    def step(sched):
+        seqs = sched.schedule()
+        t0 = time.perf_counter()
+        logits, need = runner.run(seqs)
+        dt = time.perf_counter() - t0
+        sched.postprocess(seqs, logits.float().argmax(-1).tolist() if need.numel() else [], need)
+        return dt, len(seqs)
+
+    def median(xs):
+        return sorted(xs)[len(xs) // 2]
+
+    def decode(b, ctx=128):
+        sched = engine()
+        for _ in range(b):
+            sched.add(Sequence(torch.randint(0, 10000, (ctx,), generator=g).tolist(),
+                               SamplingParams(temperature=0.6, max_tokens=64, ignore_eos=True)))
+        step(sched)                                           # prefill of all b prompts (one step: b * 128 <= 1024)
+        step(sched)                                           # warm-up decode step
+        return b / median([step(sched)[0] for _ in range(5)])
+
+    def prefill(tokens=1024):
+        times = []
+        for _ in range(6):
+            sched = engine()
+            sched.add(Sequence(torch.randint(0, 10000, (tokens + 8,), generator=g).tolist(),
+                               SamplingParams(temperature=0.6, max_tokens=8, ignore_eos=True)))
+            times.append(step(sched)[0])                      # the first chunk: exactly `tokens` new tokens, no prefix
+        return tokens / median(times[1:])
+
     t0 = time.perf_counter()
-    logits, _ = runner.run(seqs)                               # prefill (also timed: prefill tok/s)
-    prefill_s = time.perf_counter() - t0
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        toks = logits.float().argmax(-1).tolist()
-        for s, t in zip(seqs, toks):
-            s.num_cached_tokens += s.num_new_tokens
-            s.token_ids.append(t)
-            s.num_new_tokens = 1
-        logits, _ = runner.run(seqs)
-        steps += 1
-        if time.perf_counter() - t0 > budget_s and steps >= 2:
-            break
-    dt = time.perf_counter() - t0
-    return dict(value=round(b * steps / dt, 2), unit="tok/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"Qwen3-0.6B shape, decode B={b} ctx={ctx}, {steps} steps in {dt:.1f}s (oracle/ref_model.py, torch-CPU eager bf16); "
-                       f"prefill {b}x{ctx} tokens in {prefill_s:.1f}s = {b * ctx / prefill_s:.0f} tok/s",
+    b8, b1, pf = decode(8), decode(1), prefill()
+    return dict(value=round(b8, 2), unit="tok/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"Qwen3-0.6B shape through the scheduler (oracle/ref_model.py, torch-CPU eager bf16), median of 5 steps after "
+                       f"a warm-up: decode B=8 ctx=128 (= value), decode B=1 ctx=128, one 1024-token prefill chunk; {time.perf_counter() - t0:.0f}s in all",
+                decode_b8_tok_s=round(b8, 2), decode_b1_tok_s=round(b1, 2), prefill_chunk_tok_s=round(pf, 1),
                 host_cpus=os.cpu_count())
 
 
@@ -373,8 +466,6 @@ def main():
         out["native_executor"] = runner.native is not None
         if share_device:
             out["config"]["rehearsal"] = "all ranks share cuda:0; not a scaling measurement"
-    out["roofline"] = kernel_roofline(runner, seqs, iters=4)
-
     if not args.no_extras:
         # ---- decode at other batch sizes (same sequences, subsets)
         sweep = {}
@@ -439,8 +530,11 @@ def main():
             ctx_sweep[tag] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
                                   hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
         out["decode_context_sweep"] = ctx_sweep
+        if world == 1 and args.model == "qwen3-0.6b":
+            out["prefill"]["roofline"]["kernel"] = prefill_kernel_roofline(hf)
         if rank == 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(hf)
+    out["roofline"] = kernel_roofline(runner, seqs, iters=4)     # last: it overwrites the newest K/V row of every sequence
     if rank == 0:
         print(json.dumps(out))
     runner.exit()

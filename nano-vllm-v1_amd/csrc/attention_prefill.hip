@@ -13,12 +13,17 @@
 //         tile ARE the B fragment of k-step s of the next product (no lane movement);
 //   O^T += V^T . P^T A = V^T read straight from the row-major V tile with the transposing
 //                    LDS read (ds_read_b64_tr_b16), k order matched to the P fragment.
-// K/V tiles go global -> LDS by 16-byte LDS-DMA into a ring of LDS stages (2 in use; 4 measured no faster), one
-// barrier per tile and a counted vmcnt wait: the DMA of tile t+1 runs under the MFMA work of tile t; the
-// swizzles are applied to the per-lane SOURCE address because the DMA writes lane-linear.  Two workgroups fit a
-// CU (<= 256 registers, 64 KB LDS), so one's softmax overlaps the other's MFMAs.  Nothing in the tile loop may
-// make the compiler wait for vmcnt(0) (that drains the prefetch): Q fragments are pinned in registers before
-// the loop, the transposing V reads are issued from inline asm, and the loop must stay free of register spills.
+// K/V tiles go global -> LDS by 16-byte LDS-DMA (scalar base + one 32-bit lane offset per piece) into a ring of
+// STAGES steps, one barrier per step; the swizzles are applied to the per-lane SOURCE address because the DMA writes
+// lane-linear.  Each wave is software-pipelined over the steps: in iteration s it computes the scores of step s + 1
+// and then the P.V product of step s, with the softmax of step s + 1 placed between the four MFMA groups of that
+// product (MFMA and VALU work of one wave overlap; the O rescale a new maximum asks for waits until the product
+// against the old maximum is complete).  So the K half of a slot is filled one iteration ahead of its V half.
+// Nothing in the loop may make the compiler wait for vmcnt(0) on its own (that drains the prefetch): Q fragments
+// are pinned in registers before the loop, the transposing V reads and the DMA are issued from inline asm, and the
+// loop must stay free of register spills.  By counters (1024 queries x 8192 keys, 8 waves per workgroup) a wave
+// spends 36 % of its cycles issuing (about 190 vector, 210 scalar, 47 LDS instructions per 32 MFMAs), 36 % in waits
+// and barriers and 28 % stalled on dependencies; the matrix pipe is busy 31 % of the time.
 // Key groups (KS): the waves of a workgroup can be KS copies of the (query head, row block) set; copy ks takes
 // key tiles ks, ks + KS, ... of the range, every step stages KS tiles and the copies merge their (max, sum, O)
 // through LDS at the end.  That puts twice the waves on a query block without partial results leaving the CU
@@ -32,27 +37,6 @@
 
 #define LOG2E 1.4426950408889634f
 
-#ifdef NVH_ATTN_PROF
-// Tuning aid (never defined in the shipped library): per-phase cycle totals of wave 0 of every workgroup.
-__device__ unsigned long long g_attn_prof[8];
-extern "C" int32_t nvh_debug_attn_prof(unsigned long long* out, int32_t reset) {
-    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_prof), sizeof(g_attn_prof)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_prof), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#define PROF_DECL unsigned long long prof_acc[5] = {0, 0, 0, 0, 0}
-#define PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
-#define PROF_ADD(slot, a, b) prof_acc[slot] += (b) - (a)
-#define PROF_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 5; ++i_) atomicAdd(&g_attn_prof[i_], prof_acc[i_]); } while (0)
-#else
-#define PROF_DECL
-#define PROF_T(var)
-#define PROF_ADD(slot, a, b)
-#define PROF_FLUSH
-#endif
 
 template <int N>
 __device__ __forceinline__ void attn_wait_vmcnt() {
@@ -88,6 +72,7 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
     constexpr int PW = (PIECES + NW - 1) / NW;                   // pieces per wave (uniform; extras duplicate)
     constexpr int STAGE = 2 * 64 * 256;                          // K tile + V tile
     static_assert(STAGES == 2 || STAGES == 4, "the stage offset is folded into LDS addresses as a bit field");
+    static_assert(STAGES == 2 || 16 % NW == 0, "counted DMA waits need the same number of K and of V pieces in every wave");
     static_assert(KS == 1 || KS == 2, "one or two key groups");
     static_assert(KS == 1 || 32 % NW == 0, "with key groups a wave's piece i must belong to the same tile for every wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x KS x (K tile + V tile)
@@ -121,7 +106,6 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    PROF_DECL;
 
     if (kt_beg < kt_end) {
         bf16x8 qf[8];                                            // Q^T fragments, filled below
@@ -132,42 +116,75 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
         const int64_t row_stride = PAGED ? (int64_t)hkv * 128 : kv_stride;       // elements between consecutive keys
         const int dma_row = l4 * (int)row_stride + kvh * 128;                    // lane's key row inside a 4-key piece
         const int dma_ck = (pos ^ l4) * 8, dma_cv = (pos ^ (l4 << 2)) * 8;       // K: pos ^ (key & 15); V: pos ^ ((key&3)<<2 | (key>>2)&3)
-        // page id of the next tile to stage, fetched one iteration ahead so its scalar-load latency is never exposed
+        // page ids, fetched an iteration ahead of their use so the scalar-load latency is never exposed
         const int32_t* table_row = PAGED ? tables + (int64_t)b * table_stride : nullptr;
         const int last_page = PAGED ? max(lk - 1, 0) >> 8 : 0;
-        int page_ahead = 0;
-        auto fetch_page = [&](int kt) {
-            if constexpr (PAGED) page_ahead = table_row[min(kt >> 2, last_page)];
-        };
-        // Step `st` stages key tiles kt_beg + st*KS + j, j < KS, into slots (st % STAGES) * KS + j.  kt_beg is a multiple
-        // of KS and KS divides the 4 tiles of a page, so the tiles of a step share one page-table entry.  A tile past the
-        // last key of the sequence (odd tile count) re-reads the last valid tile: the DMA count per step stays uniform.
         const int last_tile = max(lk - 1, 0) >> 6;
-        auto stage = [&](int st) {
-            const int kt0 = kt_beg + st * KS;
-            LDS_AS char* base = (LDS_AS char*)smem + (st & (STAGES - 1)) * (KS * STAGE);
-            int64_t page = 0;
-            if constexpr (PAGED) {
-                page = page_ahead;                               // fetch_page(kt0) ran an iteration ago
-                fetch_page(kt0 + KS);
-            }
+        const int nsteps = (kt_end - kt_beg + KS - 1) / KS;
+        auto page_of_step = [&](int st) -> int {
+            if constexpr (PAGED) return table_row[min((kt_beg + max(st, 0) * KS) >> 2, last_page)];
+            return 0;
+        };
+        // Step s = key tiles kt_beg + s*KS + j, j < KS (kt_beg is a multiple of KS and KS divides the 4 tiles of a page, so
+        // the tiles of a step share one page-table entry).  Slot (s % 2) * KS + j holds [K tile | V tile] of that tile, but the
+        // two halves are filled one iteration apart: a wave multiplies P(s) V(s) while it computes the scores of step s + 1,
+        // so iteration s reads V(s) and K(s+1) and the DMA issued in it brings K(s+2) and V(s+1) into the halves that were
+        // read last in iteration s - 1.  A tile past the last key of the sequence (odd tile count) re-reads the last valid
+        // tile; steps past the range are skipped (every wait is vmcnt(0), so the DMA count need not be uniform).
+        // One 1-KiB piece (4 keys x 256 B): wave-uniform 64-bit base in SGPRs + one 32-bit byte offset per lane, LDS
+        // destination in M0 (saved and restored: the register belongs to the compiler).  Not counted by the compiler's
+        // own vmcnt bookkeeping - every wait on these is explicit.
+        auto dma16 = [&](const char* sbase, uint32_t lane_bytes, uint32_t lds_dst) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(lane_bytes), "s"(sbase), "s"(lds_dst) : "memory");
+        };
+        auto tile_base = [&](const bf16* ptr, int kt, int page) -> const char* {
+            int64_t tile_off;                                    // wave-uniform element offset of key kt*64
+            if constexpr (PAGED) tile_off = ((int64_t)page * NVH_KV_PAGE + (kt & 3) * 64) * row_stride;
+            else tile_off = (int64_t)(k_beg + kt * 64) * row_stride;
+            return reinterpret_cast<const char*>(ptr + tile_off);
+        };
+        // With 4, 8 or 16 waves piece i of a wave (p = i * NW + wave) belongs to the same tile and half for every wave, its
+        // keys are 4 * ((i * NW) % 16 + wave) .., and (p & 3) == (wave & 3): the lane part of the address is one register
+        // per half and everything else is a handful of scalar adds per piece.
+        constexpr bool FAST_DMA = (NW % 4 == 0) && (16 % NW == 0);
+        const uint32_t lane_k = 2u * (uint32_t)(dma_row + (dma_ck ^ (32 * (wave & 3))));
+        const uint32_t lane_v = 2u * (uint32_t)(dma_row + (dma_cv ^ (8 * (wave & 3))));
+        const uint32_t wave_piece = 8u * (uint32_t)row_stride * (uint32_t)wave;          // bytes from the tile's first key to this wave's keys
+        const uint32_t lds_base = (uint32_t)(uintptr_t)((LDS_AS char*)smem);
+        auto stage = [&](int k_step, int page_k, int v_step, int page_v) {
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
-                int p = wave + i * NW;
-                if (p >= PIECES) p -= PIECES;
-                const int kt = min(kt0 + (p >> 5), last_tile);   // (p >> 5: the same for every wave, see the static_assert)
-                int64_t tile_off;                                // wave-uniform element offset of key kt*64
-                if constexpr (PAGED) tile_off = (page * NVH_KV_PAGE + (kt & 3) * 64) * row_stride;
-                else tile_off = (int64_t)(k_beg + kt * 64) * row_stride;
-                const int isv = (p >> 4) & 1, pv = p & 15;
-                const bf16* sbase = (isv ? vp : kp) + tile_off + (int64_t)(4 * pv) * row_stride;
-                int off = dma_row + (isv ? (dma_cv ^ (8 * (pv & 3))) : (dma_ck ^ (32 * (pv & 3))));
-                if (kt * 64 + 63 >= lk) {
-                    // last, partly filled tile: keys past the end re-read the last valid key (they are masked anyway)
-                    const int over = max(kt * 64 + 4 * pv + l4 - (lk - 1), 0);
-                    off -= over * (int)row_stride;
+                // piece p = wave + i * NW of the step: key group p >> 5, K or V half (p >> 4) & 1, keys 4 (p & 15) ..
+                int p, isv, pv, jt;
+                if constexpr (FAST_DMA) {                         // i alone decides the tile and the half: compile-time constants
+                    jt = (i * NW) >> 5, isv = ((i * NW) >> 4) & 1, pv = ((i * NW) & 15) + wave;
+                    p = i * NW + wave;
+                } else {
+                    p = wave + i * NW;
+                    if (p >= PIECES) p -= PIECES;
+                    jt = p >> 5, isv = (p >> 4) & 1, pv = p & 15;
                 }
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(sbase + off), (LDS_AS void*)(base + p * 1024), 16, 0, 0);
+                const int st = isv ? v_step : k_step;             // wave-uniform
+                if (st < 0 || st >= nsteps) continue;
+                const int kt_raw = kt_beg + st * KS + jt;
+                const int kt = min(kt_raw, last_tile);
+                const uint32_t lds_dst = lds_base + (uint32_t)((st & (STAGES - 1)) * (KS * STAGE)) + (uint32_t)p * 1024u;
+                const char* tb = tile_base(isv ? vp : kp, kt, isv ? page_v : page_k);
+                if constexpr (FAST_DMA) {
+                    if (kt_raw * 64 + 63 < lk) {                  // a full tile of the sequence (all but its last one)
+                        dma16(tb + (wave_piece + 8u * (uint32_t)row_stride * (uint32_t)((i * NW) & 15)), isv ? lane_v : lane_k, lds_dst);
+                        continue;
+                    }
+                }
+                // last, partly filled tile (or a tile past the end, which re-reads the last one): keys past the last key
+                // re-read the last valid key (they are masked anyway)
+                int off = dma_row + (isv ? (dma_cv ^ (8 * (pv & 3))) : (dma_ck ^ (32 * (pv & 3))));
+                const int over = max(kt * 64 + 4 * pv + l4 - (lk - 1), 0);
+                off -= over * (int)row_stride;
+                const bf16* src = reinterpret_cast<const bf16*>(tb) + (int64_t)(4 * pv) * row_stride + off;
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)src, (LDS_AS void*)(smem + (lds_dst - lds_base)), 16, 0, 0);
             }
         };
 
@@ -176,39 +193,43 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
         //   V^T fragment (dt, t2, sft, half):          v_off(row, ch) with the row/chunk split below
         const int gi = lane >> 4, li = lane & 15;
         const int tr_q = li >> 2, tr_p = li & 3;
-        // lane parts; the (ks) / (dt, half) parts and the stage bit are wave-uniform XOR terms applied per tile
+        // lane parts; the (ks) / (dt, half) parts and the slot offset are wave-uniform XOR terms applied per tile
         const int kb0 = 256 * ql + ((hh ^ (ql & 15)) << 4);
         const int vb0 = 256 * (4 * (gi >> 1) + tr_q) + 16 * ((2 * (gi & 1) + (tr_p >> 1)) ^ ((tr_q << 2) | (gi >> 1))) + 8 * (tr_p & 1);
         LDS_AS const char* lds = (LDS_AS const char*)smem;
 
-        // One 64-key tile.  MASK: the tile crosses this wave's causal diagonal.
-        auto tile = [&](int kt, int slot, auto mask_tag) {
-            constexpr bool MASK = decltype(mask_tag)::value;
+        f32x16 st[2];                                            // scores of the tile whose softmax comes next
+        bf16x8 pb[2][2];                                         // P of the tile whose P.V product comes next
+        constexpr float RESCALE_LOG2 = 6.0f;
+
+        // ---- S^T = K . Q^T for the two 32-key halves of the tile in `slot`
+        auto s_phase = [&](int slot) {
             const int soff = slot * STAGE;
-            int kb[8], vb[4][2];
+            int kb[8];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) kb[ks] = kb0 ^ ((32 * ks) ^ soff);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int half = 0; half < 2; ++half) vb[dt][half] = vb0 ^ ((16 * ((4 * dt) ^ (2 * half))) ^ soff);
-            // ---- S^T = K . Q^T for the two 32-key halves
-            f32x16 st[2];
 #pragma unroll
             for (int t2 = 0; t2 < 2; ++t2) {
                 if (t2) __builtin_amdgcn_sched_barrier(0);      // 8 K fragments (32 registers) in flight, not 16
 #pragma unroll
-                for (int r = 0; r < 16; ++r) st[t2][r] = 0.f;
-#pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
                     if (ks == 2 || ks == 4 || ks == 6) __builtin_amdgcn_sched_barrier(0);
                     const bf16x8 kfrag = *reinterpret_cast<LDS_AS const bf16x8*>(lds + kb[ks] + 8192 * t2);
-                    st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], st[t2], 0, 0, 0);
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], ks == 0 ? zero : st[t2], 0, 0, 0);   // (zero: an inline operand)
                 }
             }
-            // ---- causal mask, online softmax (query on the lane).  Scores stay unscaled: the scale is
-            // folded into the exponent, p = exp2(s * scale*log2e - m), one FMA per element.
-            if constexpr (MASK) {
+        };
+        // ---- online softmax of st (query on the lane), in three slices so that they can sit between the MFMA groups of
+        // the P.V product of the previous tile.  Scores stay unscaled: p = exp2(s * scale*log2e - m), one FMA per element.
+        // The running max only moves when some query's max grew by more than 2^RESCALE_LOG2 (below that p <= 2^RESCALE_LOG2
+        // is still exact enough in bf16 / fp32); the O rescale it asks for is applied by the caller once the P.V product
+        // that is in flight against the old max has finished.
+        float alpha = 1.0f, neg_m = 0.f;
+        bool resc = false;
+        f32x2 psum2 = {0.f, 0.f};
+        auto sm_max = [&](int kt, bool masked) {
+            if (masked) {
                 const int vis = qrow + shift - kt * 64 - 4 * hh;   // last visible key, relative to the lane's first
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2)
@@ -216,84 +237,101 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
                     for (int r = 0; r < 16; ++r)
                         st[t2][r] = (t2 * 32 + (r & 3) + 8 * (r >> 2)) > vis ? -INFINITY : st[t2][r];
             }
-            float mx = -INFINITY;
+            float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t2][r]);
+            for (int r = 0; r < 16; ++r) {
+                mx0 = fmaxf(mx0, st[0][r]);
+                mx1 = fmaxf(mx1, st[1][r]);
+            }
+            float mx = fmaxf(mx0, mx1);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;
-            // The running max only moves when some query's max grew by more than 2^RESCALE_LOG2: below
-            // that, p <= 2^RESCALE_LOG2 is still exact enough in bf16/fp32 and the O rescale is skipped.
-            constexpr float RESCALE_LOG2 = 6.0f;
-            float alpha = 1.0f;
-            if (__any(mx > m_run + RESCALE_LOG2)) {
+            resc = __any(mx > m_run + RESCALE_LOG2);
+            alpha = 1.0f;
+            if (resc) {
                 const float m_new = fmaxf(m_run, mx);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
                 alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-                asm volatile("" : "+v"(alpha));                 // opaque: keeps the 64 multiplies inside this rare branch
                 m_run = m_new;
+            }
+            neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
+            psum2 = f32x2{0.f, 0.f};
+        };
+        auto sm_exp = [&](int t2, bf16x8 (&pn)[2][2]) {
+            const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {neg_m, neg_m};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 s2 = {st[t2][r], st[t2][r + 1]};
+                const f32x2 e2 = __builtin_elementwise_fma(s2, sc2, nm2);
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
+                psum2 += p2;
+                pn[t2][r >> 3][r & 7] = f2bf(p2[0]);
+                pn[t2][r >> 3][(r & 7) + 1] = f2bf(p2[1]);
+            }
+        };
+        auto sm_finish = [&]() { l_run = l_run * alpha + (psum2[0] + psum2[1]); };
+        auto rescale_o = [&]() {
+            if (resc) {                                          // wave-uniform, rare
+                asm volatile("" : "+v"(alpha));                 // opaque: keeps the 64 multiplies inside this branch
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
-            const float neg_m = (m_run == -INFINITY) ? 0.f : -m_run;
-            const f32x2 sc2 = {scale_log2, scale_log2}, nm2 = {neg_m, neg_m};
-            f32x2 psum2 = {0.f, 0.f};
-            bf16x8 pb[2][2];
+        };
+        // ---- one 32-column block dt of O^T += V^T . P^T over the 64 keys of the tile in `slot`.  The transposing LDS reads
+        // are issued from inline asm: as compiler-visible loads they would each be preceded by a vmcnt(0) (LDS reads are
+        // ordered after every LDS-DMA in flight), which drains the prefetched tiles.  lgkmcnt(0) is the only wait (LDS
+        // returns in order; over-waiting is safe).
+        auto pv_block = [&](int slot, int dt, const bf16x8 (&pc)[2][2]) {
+            const int soff = slot * STAGE;
+            const int v0 = vb0 ^ ((16 * ((4 * dt) ^ 0)) ^ soff), v1 = vb0 ^ ((16 * ((4 * dt) ^ 2)) ^ soff);
+            bf16x4 vl[4], vh[4];
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %8 offset:16384\n\t"
+                "ds_read_b64_tr_b16 %1, %9 offset:18432\n\t"
+                "ds_read_b64_tr_b16 %2, %8 offset:20480\n\t"
+                "ds_read_b64_tr_b16 %3, %9 offset:22528\n\t"
+                "ds_read_b64_tr_b16 %4, %8 offset:24576\n\t"
+                "ds_read_b64_tr_b16 %5, %9 offset:26624\n\t"
+                "ds_read_b64_tr_b16 %6, %8 offset:28672\n\t"
+                "ds_read_b64_tr_b16 %7, %9 offset:30720\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(vl[0]), "=&v"(vh[0]), "=&v"(vl[1]), "=&v"(vh[1]), "=&v"(vl[2]), "=&v"(vh[2]), "=&v"(vl[3]), "=&v"(vh[3])
+                : "v"(v0), "v"(v1)
+                : "memory");
+            __builtin_amdgcn_sched_barrier(0);                   // no MFMA above the wait
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const f32x2 s2 = {st[t2][r], st[t2][r + 1]};
-                    const f32x2 e2 = __builtin_elementwise_fma(s2, sc2, nm2);
-                    const f32x2 p2 = {__builtin_amdgcn_exp2f(e2[0]), __builtin_amdgcn_exp2f(e2[1])};
-                    psum2 += p2;
-                    pb[t2][r >> 3][r & 7] = f2bf(p2[0]);
-                    pb[t2][r >> 3][(r & 7) + 1] = f2bf(p2[1]);
-                }
-            l_run = l_run * alpha + (psum2[0] + psum2[1]);
-            // ---- O^T += V^T . P^T.  The transposing LDS reads are issued from inline asm: as compiler-visible loads
-            // they would each be preceded by a vmcnt(0) (LDS reads are ordered after every LDS-DMA in flight), which
-            // drains the prefetched tiles.  One group = the 4 reads that feed two MFMAs (the SIMD's other wave covers their
-            // latency).  lgkmcnt(0) is the only wait (LDS returns in order; over-waiting is safe).
-            bf16x4 vl[2], vh[2];
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {                  // rows 32*t2 + 16*sft (+8 for the high half)
-                    if (t2 == 0)
-                        asm volatile(
-                            "ds_read_b64_tr_b16 %0, %4 offset:16384\n\t"
-                            "ds_read_b64_tr_b16 %1, %5 offset:18432\n\t"
-                            "ds_read_b64_tr_b16 %2, %4 offset:20480\n\t"
-                            "ds_read_b64_tr_b16 %3, %5 offset:22528\n\t"
-                            "s_waitcnt lgkmcnt(0)"
-                            : "=&v"(vl[0]), "=&v"(vh[0]), "=&v"(vl[1]), "=&v"(vh[1])
-                            : "v"(vb[dt][0]), "v"(vb[dt][1])
-                            : "memory");
-                    else
-                        asm volatile(
-                            "ds_read_b64_tr_b16 %0, %4 offset:24576\n\t"
-                            "ds_read_b64_tr_b16 %1, %5 offset:26624\n\t"
-                            "ds_read_b64_tr_b16 %2, %4 offset:28672\n\t"
-                            "ds_read_b64_tr_b16 %3, %5 offset:30720\n\t"
-                            "s_waitcnt lgkmcnt(0)"
-                            : "=&v"(vl[0]), "=&v"(vh[0]), "=&v"(vl[1]), "=&v"(vh[1])
-                            : "v"(vb[dt][0]), "v"(vb[dt][1])
-                            : "memory");
-#pragma unroll
-                    for (int sft = 0; sft < 2; ++sft) {
-                        const bf16x8 vfrag = __builtin_shufflevector(vl[sft], vh[sft], 0, 1, 2, 3, 4, 5, 6, 7);
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pb[t2][sft], o[dt], 0, 0, 0);
-                    }
-                }
+            for (int u = 0; u < 4; ++u) {                        // u = 2*t2 + sft: keys 32*t2 + 16*sft ..
+                const bf16x8 vfrag = __builtin_shufflevector(vl[u], vh[u], 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pc[u >> 1][u & 1], o[dt], 0, 0, 0);
+            }
         };
 
-        constexpr int AHEAD = STAGES - 1;                       // steps kept in flight
-        const int nsteps = (kt_end - kt_beg + KS - 1) / KS;
-        fetch_page(kt_beg);
-        for (int t = 0; t < AHEAD && t < nsteps; ++t) stage(t);
+        // this wave's tile of step s: its key tile, whether it exists / is visible, whether it crosses the causal diagonal
+        auto tile_of = [&](int s) { return kt_beg + s * KS + ks_id; };
+        auto tile_valid = [&](int s) { return s < nsteps && tile_of(s) < kt_end && tile_of(s) * 64 <= wave_last_key; };
+        auto tile_masked = [&](int s) { return tile_of(s) * 64 + 63 > wave_first_row + shift; };
+        auto slot_of = [&](int s) { return (s & (STAGES - 1)) * KS + ks_id; };
+        // DMA ring of STAGES steps: iteration s issues K(s + STAGES) and V(s + STAGES - 1) into the halves read last in
+        // iteration s - 1, and needs what iteration s + 1 - STAGES issued (K(s+1), V(s)): the issues of the STAGES - 2
+        // iterations in between may stay in flight.  The count only holds while those iterations issued all their pieces;
+        // near the end of the range (and for wave counts that split K and V pieces unevenly) the wait is for everything.
+        auto wait_for_iteration = [&](int s) {
+            if constexpr (STAGES > 2) {
+                if (s + STAGES <= nsteps) {
+                    attn_wait_vmcnt<PW * (STAGES - 2)>();
+                    return;
+                }
+            }
+            attn_wait_vmcnt<0>();
+        };
+
+        // ---- prologue: K(0), then what iterations 1 - STAGES .. -1 would have issued; scores and softmax of step 0 with
+        // nothing to overlap
+        int page_ring[STAGES + 1];                               // pages of steps s + 1 .. s + STAGES + 1 at the top of iteration s
+#pragma unroll
+        for (int j = 0; j <= STAGES; ++j) page_ring[j] = page_of_step(j);
+        stage(0, page_ring[0], -1, 0);
         // Q^T fragments: lane (q = ql, half hh) holds Q[q][16ks + 8hh .. +7].  Loaded AFTER the first DMAs were
         // issued (the latencies overlap) and pinned by an empty asm: from here on the compiler sees registers, not a
         // pending global load, so it does not drain the DMA queue (vmcnt(0)) at their first use in every tile.
@@ -304,29 +342,64 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
         }
-        for (int st = 0; st < nsteps; ++st) {
-            // this wave's pieces of step st have landed (later steps may still be in flight) ...
-            PROF_T(p0);
-            attn_wait_tiles<PW, AHEAD - 1>(min(AHEAD - 1, nsteps - 1 - st));
+#pragma unroll
+        for (int j = 1; j < STAGES; ++j) stage(j, page_ring[j], j - 1, page_ring[j - 1]);
+        if (STAGES > 2 && STAGES <= nsteps) attn_wait_vmcnt<PW * (STAGES - 1)>();      // K(0) landed, full issues behind it
+        else attn_wait_vmcnt<0>();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // (page_ring[j] is now the page of step j; at the top of iteration s it is shifted to hold steps s .. s + STAGES)
+        if (tile_valid(0)) {
+            s_phase(slot_of(0));
+            sm_max(tile_of(0), tile_masked(0));
+            sm_exp(0, pb);
+            sm_exp(1, pb);
+            sm_finish();
+            rescale_o();                                         // (O is still zero: keeps the state consistent)
+        }
+        // iteration s: P.V of step s from pb, scores + softmax of step s + 1 into pn, which then becomes pb
+        for (int s = 0; s < nsteps; ++s) {
+            // V(s) and K(s+1) have landed for this wave ...
+            wait_for_iteration(s);
             asm volatile("" ::: "memory");
-            PROF_T(p1);
-            __builtin_amdgcn_s_barrier();                       // ... everyone's have, and step st-1 is consumed
+            __builtin_amdgcn_s_barrier();                       // ... for everyone, and the halves read in iteration s-1 are free
             asm volatile("" ::: "memory");
-            PROF_T(p2);
-            if (st + AHEAD < nsteps) stage(st + AHEAD);         // into the slots of step st-1
-            PROF_T(p3);
-            PROF_ADD(0, p0, p1);
-            PROF_ADD(1, p1, p2);
-            PROF_ADD(2, p2, p3);
-            const int kt = kt_beg + st * KS + ks_id;            // this key group's tile of the step
-            if (kt < kt_end && kt * 64 <= wave_last_key) {      // else: no such tile, or entirely above this wave's diagonal
-                const int slot = (st & (STAGES - 1)) * KS + ks_id;
-                if (kt * 64 + 63 > wave_first_row + shift) tile(kt, slot, std::true_type{});
-                else tile(kt, slot, std::false_type{});
+            stage(s + STAGES, page_ring[STAGES], s + STAGES - 1, page_ring[STAGES - 1]);
+#pragma unroll
+            for (int j = 0; j < STAGES; ++j) page_ring[j] = page_ring[j + 1];
+            page_ring[STAGES] = page_of_step(s + STAGES + 1);
+            if (!tile_valid(s)) continue;                        // (wave-uniform; the valid steps of a wave are a prefix)
+            const int vslot = slot_of(s);
+            if (tile_valid(s + 1)) {
+                // scores of the next tile, then its softmax in the shadow of this tile's P.V MFMAs
+                s_phase(slot_of(s + 1));
+                bf16x8 pn[2][2];
+                __builtin_amdgcn_sched_barrier(0);
+                pv_block(vslot, 0, pb);
+                __builtin_amdgcn_sched_barrier(0);
+                sm_max(tile_of(s + 1), tile_masked(s + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                pv_block(vslot, 1, pb);
+                __builtin_amdgcn_sched_barrier(0);
+                sm_exp(0, pn);
+                __builtin_amdgcn_sched_barrier(0);
+                pv_block(vslot, 2, pb);
+                __builtin_amdgcn_sched_barrier(0);
+                sm_exp(1, pn);
+                __builtin_amdgcn_sched_barrier(0);
+                pv_block(vslot, 3, pb);
+                __builtin_amdgcn_sched_barrier(0);
+                sm_finish();
+                rescale_o();                                     // after the whole product against the old max
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) pb[t2][k2] = pn[t2][k2];
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) pv_block(vslot, dt, pb);
             }
-            PROF_T(p4);
-            PROF_ADD(3, p3, p4);
-            PROF_ADD(4, p0, p0 + 1);
         }
     }
 
@@ -357,7 +430,6 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
         m_run = m_new;
     }
 
-    PROF_FLUSH;
     // ---- lane (q, hh) holds O[q][32dt + 8(r>>2) + 4hh + (r&3)]
     l_run += __shfl_xor(l_run, 32, 64);
     if (qrow_raw >= lq) return;
@@ -495,17 +567,20 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
     VarlenArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, q_token_stride, kv_token_stride, cu_seqlens_q, cu_seqlens_k,
                  block_tables, table_stride, (int)num_kv_heads, softmax_scale * LOG2E, (bf16*)out, num_splits,
                  (int)(nvh_cdiv(nvh_cdiv(tiles, num_splits), ks) * ks), ws_acc, ws_ml};
-#define LAUNCH_VL(GG, RBB, KSS)                                                                                             \
+#define LAUNCH_VL(GG, RBB, KSS, STG)                                                                                        \
     do {                                                                                                                    \
         dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));      \
-        launch_varlen<GG, RBB, KSS, 2>(paged, grid, st, a);                                                                 \
+        launch_varlen<GG, RBB, KSS, STG>(paged, grid, st, a);                                                               \
     } while (0)
     switch (g) {
-        case 1: if (ks == 2) LAUNCH_VL(1, 4, 2); else LAUNCH_VL(1, 4, 1); break;
-        case 2: if (ks == 2) LAUNCH_VL(2, 2, 2); else LAUNCH_VL(2, 2, 1); break;   // 32- and 128-row blocks measured slower
-        case 4: if (ks == 2) LAUNCH_VL(4, 1, 2); else LAUNCH_VL(4, 1, 1); break;
-        case 5: LAUNCH_VL(5, 1, 1); break;
-        case 8: LAUNCH_VL(8, 1, 1); break;
+        case 1: if (ks == 2) LAUNCH_VL(1, 4, 2, 2); else LAUNCH_VL(1, 4, 1, 2); break;
+        // measured and not kept for 2 query heads per kv head: 32-row blocks (twice the K/V staging per MFMA), 128-row
+        // blocks (half the workgroups; 99.9 us against 98 at 8192 keys in 4 ranges) and a ring of 4 steps instead of 2 (no
+        // change: the loop is bound by instruction issue, not by the DMA latency)
+        case 2: if (ks == 2) LAUNCH_VL(2, 2, 2, 2); else LAUNCH_VL(2, 2, 1, 2); break;
+        case 4: if (ks == 2) LAUNCH_VL(4, 1, 2, 2); else LAUNCH_VL(4, 1, 1, 2); break;
+        case 5: LAUNCH_VL(5, 1, 1, 2); break;
+        case 8: LAUNCH_VL(8, 1, 1, 2); break;
         default:
             nvh_set_error("nvh_attn_varlen: group size Hq/Hkv = %d unsupported (1,2,4,5,8)", g);
             return NVH_ENOSYS;
