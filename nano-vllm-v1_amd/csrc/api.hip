@@ -25,6 +25,9 @@ extern "C" int32_t nvh_device_check(int32_t device_index) {
     // set-up for nvh_attn_decode_noalloc: resolve this GPU's copy of its built-in array now when the checked device is
     // the current one (otherwise the entry point does it on its first call there)
     int cur = -1;
-    if (hipGetDevice(&cur) == hipSuccess && cur == device_index) return nvh_noalloc_scratch(nullptr);
+    if (hipGetDevice(&cur) == hipSuccess && cur == device_index) {
+        const int32_t rc = nvh_noalloc_scratch(nullptr);
+        return rc != NVH_OK ? rc : nvh_decode_arrivals(nullptr);
+    }
     return NVH_OK;
 }

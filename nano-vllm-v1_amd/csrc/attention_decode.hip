@@ -14,6 +14,7 @@
 // finishes them.  So one launch serves a batch of short sequences with a few very long ones without making the
 // short ones pay for partial results, and without the long ones walking their keys in a single workgroup.
 #include "common.h"
+#include <stdlib.h>
 
 #define LOG2E 1.4426950408889634f
 
@@ -47,13 +48,18 @@ struct FusedQkv {
     float eps;
 };
 
+__device__ __forceinline__ void merge_row_wave(const float* __restrict__ ws_acc, const float* __restrict__ ws_ml, bf16* __restrict__ out,
+                                               int num_splits, int64_t bh, int active, int lane);
+
 template <int G, bool FUSED>
 __global__ __launch_bounds__(256) void attn_decode_kernel(
     const bf16* __restrict__ q, int64_t q_stride, bf16* __restrict__ kc, bf16* __restrict__ vc,
     const int32_t* __restrict__ ctx_lens, const int32_t* __restrict__ tables, int64_t table_stride, int hkv,
-    float scale_log2, bf16* __restrict__ out, float* __restrict__ ws_acc, float* __restrict__ ws_ml, int min_range, DecodeItems items, FusedQkv fz) {
+    float scale_log2, bf16* __restrict__ out, float* __restrict__ ws_acc, float* __restrict__ ws_ml, int min_range, DecodeItems items, FusedQkv fz,
+    unsigned* __restrict__ arrivals) {
     __shared__ float sm_acc[4][G][128];
     __shared__ float sm_ml[4][G][2];
+    __shared__ int sm_last;
 
     const int kvh = blockIdx.y;
     const int hq = hkv * G;
@@ -217,14 +223,36 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
         if (final_here) {
             out[((int64_t)b * hq + h) * 128 + d] = f2bf(L > 0.f ? A / L : 0.f);
         } else {
+            // write-through (agent-scope) stores: the partial results need no release fence before the arrival count
             const int64_t slab = ((int64_t)b * hq + h) * num_splits + split;
-            ws_acc[slab * 128 + d] = A;
+            __hip_atomic_store(ws_acc + slab * 128 + d, A, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == 0) {
-                ws_ml[slab * 2] = M;
-                ws_ml[slab * 2 + 1] = L;
+                __hip_atomic_store(ws_ml + slab * 2, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ws_ml + slab * 2 + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
+    if (final_here || arrivals == nullptr) return;           // block-uniform
+    // The workgroup that finishes last among the `active` ranges of this (sequence, kv head) merges them - no second
+    // launch.  Every storing wave drains its stores, one lane counts the arrival (agent-scope atomic), the last arriver
+    // invalidates its CU's L1 (agent-scope acquire) before any wave of it reads the other workgroups' records, and puts
+    // the counter back to zero for the next launch.  Placement- and order-independent.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* cnt = arrivals + (int64_t)b * hkv + kvh;
+        const unsigned before = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = before + 1u == (unsigned)active;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        sm_last = last;
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    for (int g = w; g < G; g += 4) merge_row_wave(ws_acc, ws_ml, out, num_splits, (int64_t)b * hq + kvh * G + g, active, lane);
 }
 
 // Merge per-range partials of one output row (sequence/token x query head).  Both kernels below compute the same
@@ -382,6 +410,28 @@ __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const floa
     }
 }
 
+// Arrival counters of the in-kernel merge: one word per (sequence, kv head), zero when the code object is loaded and
+// put back to zero by every merge, so no launch has to clear them.  One copy per GPU; launches that overlap on a GPU
+// (two streams) would share them and must not.
+#define NVH_DECODE_ARRIVALS 65536
+static __device__ __align__(256) unsigned decode_arrivals[NVH_DECODE_ARRIVALS];
+namespace {
+unsigned* g_arrivals_ptr[64] = {};
+}
+int32_t nvh_decode_arrivals(unsigned** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    NVH_REQUIRE(e == hipSuccess && dev >= 0 && dev < 64, NVH_ELAUNCH, "nvh_attn_decode: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    if (g_arrivals_ptr[dev] == nullptr) {
+        unsigned* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(decode_arrivals));
+        NVH_REQUIRE(e == hipSuccess && p != nullptr, NVH_ELAUNCH, "nvh_attn_decode: hipGetSymbolAddress on device %d: %s", dev, hipGetErrorString(e));
+        g_arrivals_ptr[dev] = p;
+    }
+    if (out) *out = g_arrivals_ptr[dev];
+    return NVH_OK;
+}
+
 int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits,
                                 const int32_t* ctx_lens, int hq, int min_range, const int32_t* seq_active, hipStream_t st) {
     if (seq_active != nullptr && rows / hq > 16)
@@ -450,10 +500,19 @@ int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz)
         grid = dim3(1, (unsigned)a.num_kv_heads, (unsigned)a.num_items);
     }
     const float sl2 = a.softmax_scale * LOG2E;
+    // NVH_DECODE_MERGE_IN_LAUNCH=1: key ranges are merged by the last workgroup to arrive instead of by a second launch
+    // (same bits).  Off by default: measured on Qwen3-0.6B decode steps it loses at 1 sequence (1.286 ms against 1.170 ms
+    // per step: the drain, the arrival atomic, the acquire and a merge by one workgroup cost more than the 4.7 us launch
+    // they replace) and gains under 1 % at 32 sequences (1.909 against 1.926 ms).
+    unsigned* arrivals = nullptr;
+    if (a.num_splits > 1 && a.batch * a.num_kv_heads <= NVH_DECODE_ARRIVALS && getenv("NVH_DECODE_MERGE_IN_LAUNCH") != nullptr) {
+        const int32_t rc = nvh_decode_arrivals(&arrivals);
+        if (rc != NVH_OK) return rc;
+    }
 #define LAUNCH_DEC(GG)                                                                                                  \
     attn_decode_kernel<GG, FUSED><<<grid, 256, 0, a.st>>>((const bf16*)a.q, a.q_token_stride, (bf16*)a.k_cache, (bf16*)a.v_cache, \
                                                           a.context_lens, a.block_tables, a.table_stride, (int)a.num_kv_heads, \
-                                                          sl2, (bf16*)a.out, ws_acc, ws_ml, min_range, a.items, fz)
+                                                          sl2, (bf16*)a.out, ws_acc, ws_ml, min_range, a.items, fz, arrivals)
     switch (g) {
         case 1: LAUNCH_DEC(1); break;
         case 2: LAUNCH_DEC(2); break;
@@ -466,7 +525,7 @@ int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz)
     }
 #undef LAUNCH_DEC
     NVH_CHECK_LAUNCH(name);
-    if (a.num_splits > 1)
+    if (a.num_splits > 1 && arrivals == nullptr)
         return nvh_launch_attn_combine(ws_acc, ws_ml, a.out, a.batch * a.num_q_heads, a.num_splits, a.context_lens, (int)a.num_q_heads,
                                        min_range, a.items.seq_active, a.st);
     return NVH_OK;

@@ -45,6 +45,9 @@ int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* o
 // Device address, on the current GPU, of the built-in partial-result array of nvh_attn_decode_noalloc (resolved on
 // first use; nvh_device_check resolves it ahead of time for callers that will run under graph capture).
 int32_t nvh_noalloc_scratch(float** out);
+// Device address, on the current GPU, of the arrival counters the decode attention uses to merge key ranges in its own
+// launch (resolved on first use, or by nvh_device_check before a graph capture).
+int32_t nvh_decode_arrivals(unsigned** out);
 
 static inline bool nvh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int64_t nvh_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

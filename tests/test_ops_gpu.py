@@ -595,3 +595,45 @@ def test_sample_noise_is_never_zero(ops):
     for offset in range(4):
         ids = ops.sample(dl, dt, seed=1234, offset=offset)
         assert ids.cpu().tolist() == [7] * rows, f"offset {offset}: {(ids.cpu() != 7).sum().item()} rows left the leading column"
+
+
+def test_attn_decode_in_launch_merge_equals_merge_launch(ops):
+    """With NVH_DECODE_MERGE_IN_LAUNCH=1 key ranges are merged by the last workgroup of a (sequence, kv head) to arrive,
+    inside the attention launch; it must give the bits of the separate merge launch (the default).  Checked on every launch of a run of
+    back-to-back launches with other kernels between them (the hand-off between workgroups has to hold under load and
+    with warm caches), on uneven contexts, for three group sizes, the fused-qkv variant and the work list."""
+    import os
+    d = 128
+    for hq, hkv, splits in ((16, 8, 8), (10, 2, 5), (8, 1, 16)):
+        g = torch.Generator().manual_seed(hq)
+        lens_k = torch.randint(1, 3000, (48,), generator=g).tolist()
+        lens_k[5], lens_k[11], lens_k[40] = 0, 1, 4096
+        b = len(lens_k)
+        q, kc, vc, bt, _, _ = _paged_case(200 + hq, [1] * b, lens_k, hq, hkv, num_pages=sum((n + 255) // 256 for n in lens_k) + 1)
+        dq, dkc, dvc, dbt = dev(q), dev(kc), dev(vc), dev(bt)
+        ctx = dev(torch.tensor(lens_k, dtype=torch.int32))
+        scale = d ** -0.5
+        want = ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, num_splits=splits).clone()
+        x, w = dev(rnd(256, 1024, seed=1)), dev(rnd(1024, 1024, seed=2, scale=0.05))
+        outs = []
+        os.environ["NVH_DECODE_MERGE_IN_LAUNCH"] = "1"
+        try:
+            for it in range(12):
+                outs.append(ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, num_splits=splits))
+                ops.linear(x, w)                                  # other work between the launches
+        finally:
+            os.environ.pop("NVH_DECODE_MERGE_IN_LAUNCH")
+        for it, got in enumerate(outs):
+            assert torch.equal(got, want), f"launch {it}: {int((got != want).sum())} elements differ (hq {hq}, hkv {hkv})"
+        ref = R.attention_decode(q, kc, vc, torch.tensor(lens_k, dtype=torch.int32), bt, scale)
+        assert_close(want, ref, 1.5e-2, 2e-2)
+        # work list: the same comparison
+        plan = ops.plan_decode_items(lens_k, max_ranges=16, range_keys=256, capacity=b + 64)
+        items = ops.upload_decode_items(plan, "cuda")
+        want_items = ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, items=items).clone()
+        os.environ["NVH_DECODE_MERGE_IN_LAUNCH"] = "1"
+        try:
+            for it in range(4):
+                assert torch.equal(ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, items=items), want_items)
+        finally:
+            os.environ.pop("NVH_DECODE_MERGE_IN_LAUNCH")
