@@ -147,11 +147,43 @@ class Driver:
             toks = t.tolist()
         return toks
 
-    def decode_step(self, seqs):
+    def schedule_decode(self, seqs):
         for s in seqs:
             s.num_new_tokens = 1
             if len(s.block_table) * PAGE <= s.num_cached_tokens:     # the new token starts a page
                 self.grow(s, s.num_cached_tokens + 1)
+
+    def decode_steps_ahead(self, seqs, steps):
+        """`steps` decode steps the way the engine runs them with Config.async_scheduling (LLMEngine._step_ahead):
+        step n+1 is scheduled and launched - its input ids fed from step n's sampler output on the device - before
+        step n's ids are read back.  Same launches, same ids as `decode_step`; the host work hides behind the GPU."""
+        from nanovllm.engine.sequence import PLACEHOLDER
+        inflight = None
+
+        def fill(entry):
+            tokens, positions = entry
+            for s, pos, t in zip(seqs, positions, tokens.result()):
+                s.token_ids[pos] = t
+                s.last_token = s.token_ids[-1]
+
+        for _ in range(steps):
+            self.schedule_decode(seqs)
+            tokens = self.runner.run_async(seqs)
+            positions = []
+            for row, s in enumerate(seqs):
+                s.num_cached_tokens += 1
+                s.num_new_tokens = 0
+                s.append_token(PLACEHOLDER)
+                s.pending_slot = row
+                positions.append(len(s) - 1)
+            if inflight is not None:
+                fill(inflight)
+            inflight = (tokens, positions)
+        if inflight is not None:
+            fill(inflight)
+
+    def decode_step(self, seqs):
+        self.schedule_decode(seqs)
         toks, need = self.runner.run(seqs)
         toks = self.share_tokens(toks, len(seqs))
         for s, t in zip(seqs, toks):                                  # ids arrive as Python ints
@@ -179,13 +211,18 @@ def sync_all(distributed, runner=None):
         runner.comm.check()                     # raises if an exchange timed out instead of reporting a bogus time
 
 
-def time_decode(driver, seqs, steps, warmup, distributed):
+def time_decode(driver, seqs, steps, warmup, distributed, ahead=False):
+    """Seconds for `steps` decode steps (max over the ranks).  `ahead`: the engine loop that runs one step ahead of
+    its sampled ids (single rank only); its last step's ids are read back inside the timed region."""
     for _ in range(warmup):
         driver.decode_step(seqs)
     sync_all(distributed, driver.runner)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        driver.decode_step(seqs)
+    if ahead:
+        driver.decode_steps_ahead(seqs, steps)
+    else:
+        for _ in range(steps):
+            driver.decode_step(seqs)
     sync_all(distributed, driver.runner)
     dt = time.perf_counter() - t0
     if distributed:
@@ -249,6 +286,7 @@ def kernel_roofline(runner, seqs, iters):
                 launches_timed=n)
 
 
+@torch.inference_mode()
 def prefill_kernel_roofline(hf, tokens=1024, iters=3):
     """The kernels of one 1024-token prefill chunk (no cached prefix), each timed with HIP events on the launch stream
     over rotating weight copies (a layer's weights are cold when its kernels run): flops, time and fraction of the bf16
@@ -405,7 +443,7 @@ def main():
     b, ctx0 = args.batch, args.context
     total_steps = args.steps + args.warmup
     max_len = 8192 + 64
-    pages_decode = b * ((ctx0 + total_steps + 64 + PAGE) // PAGE + 1)
+    pages_decode = b * ((ctx0 + total_steps + 64 + PAGE) // PAGE + 3)          # room for the comparison runs and sweeps too
     pages = max(pages_decode, 8 * (max_len // PAGE + 1)) + 16
     model_dir = MODEL_DIR.parent / args.model
     model_name = args.model.replace("qwen3", "Qwen3").replace("b", "B")
@@ -438,7 +476,10 @@ def main():
                    note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included")
 
     # ---- the timed region: K decode steps of B sequences
-    dt = time_decode(driver, seqs, args.steps, args.warmup, distributed)
+    # One rank: the engine loop that runs one step ahead of its sampled ids (Config.async_scheduling), the fastest way
+    # this engine serves a decode batch; the synchronous loop of the reference is timed right after, for comparison.
+    ahead = not distributed and os.environ.get("NANOVLLM_BENCH_SYNC", "0") != "1"
+    dt = time_decode(driver, seqs, args.steps, args.warmup, distributed, ahead=ahead)
     note("decode timed")
     value = b * args.steps / dt
     contexts = [s.num_cached_tokens - args.steps / 2 for s in seqs]          # mean context over the timed steps
@@ -450,11 +491,17 @@ def main():
                dtype="bf16", data=f"synthetic token ids, random-init weights ({model_name} architecture)",
                config=dict(workload=f"{model_name} TP={world} bf16 decode, B={b} sequences x ~{ctx0} context tokens, "
                                     "chunked_prefill on, max_num_batched_tokens=1024, hipGraph decode",
-                           batch=b, context=ctx0, parallelism=f"tp{world}", kv_page=PAGE),
+                           batch=b, context=ctx0, parallelism=f"tp{world}", kv_page=PAGE,
+                           engine_loop=("one step ahead (Config.async_scheduling): step n+1 is launched before step n's ids are read back"
+                                        if ahead else "synchronous (schedule, run, read ids back, postprocess)")),
                step_roofline=dict(bound="hbm", achieved=round(step_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(step_gbs / HBM_PEAK_GBS, 4), bytes_per_step=int(step_bytes),
                                   weight_bytes=int(w_bytes), kv_bytes_per_context_token=int(kv_tok)),
                prefill=prefill, init_s=round(init_s, 1))
+    if ahead:
+        d_sync = time_decode(driver, seqs, args.steps, 2, distributed)
+        out["synchronous_loop"] = dict(tok_s=round(b * args.steps / d_sync, 1), ms_per_step=round(d_sync / args.steps * 1e3, 4),
+                                       note="same steps with the ids read back before the next step is scheduled (contexts one timed region longer)")
     if distributed:
         from nanovllm import comm as comm_mod
         out["tp_exchange"] = ("xgmi peer all-reduce (one kernel per projection, inside the native step and its hipGraph)"
@@ -474,11 +521,13 @@ def main():
                 continue
             sub = seqs[:bb]
             k = 32
-            d2 = time_decode(driver, sub, k, 4, distributed)
+            d2 = time_decode(driver, sub, k, 4, distributed, ahead=ahead)
             sb, _, _ = algorithmic_bytes_per_decode_step(hf, [s.num_cached_tokens - k / 2 for s in sub], world)
             note(f"sweep B={bb} done")
             sweep[f"B{bb}"] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
                                    hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
+            if ahead:
+                sweep[f"B{bb}"]["ms_per_step_synchronous_loop"] = round(time_decode(driver, sub, k, 2, distributed) / k * 1e3, 4)
         out["decode_sweep"] = sweep
         # ---- long-context chunked prefill: 8192-token prompts, 8 chunks of 1024 each
         driver_pages = driver.next_page

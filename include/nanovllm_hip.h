@@ -118,6 +118,14 @@ int32_t nvh_embedding(const int64_t* ids, const void* table, void* out, int64_t 
 int32_t nvh_gather_last_rows(const void* hidden, const int32_t* cu_seqlens_q, const int32_t* need,
                              void* out, int64_t num_rows, int64_t dim, nvh_stream_t stream);
 
+/* input_ids[dst_index[i]] = sampled[src_index[i]] for i < count.  No counterpart in the reference, whose step reads
+ * the sampled ids back (engine/llm_engine.py:117-126 -> scheduler.postprocess) before it builds the next step's
+ * input_ids (engine/model_runner.py:438-495): an engine that schedules one step ahead launches the next step first
+ * and lets it take those ids from the sampler's output on the device.  The indices must be in range (not checked
+ * on the device). */
+int32_t nvh_feed_token_ids(int64_t* input_ids, const int32_t* dst_index, const int64_t* sampled,
+                           const int32_t* src_index, int64_t count, nvh_stream_t stream);
+
 /* ---- G1-G5: y[M,N] = x[M,K] @ W[N,K]^T (+ bias[N]), fp32 accumulation, bf16 out.
  * layers/linear.py:130,198,407 and layers/embed_head.py:204 (F.linear -> cuBLAS).
  * K % 64 == 0.  split_k > 1: fp32 partial slabs [split_k, M, N] are written to `workspace`

@@ -528,3 +528,21 @@ extern "C" int32_t nvh_gather_last_rows(const void* hidden, const int32_t* cu_se
     NVH_CHECK_LAUNCH("gather_last_rows");
     return NVH_OK;
 }
+
+// input_ids[dst[i]] = sampled[src[i]]: the token ids a step takes from the previous step's sampler output while the
+// host has not read them back yet.
+__global__ __launch_bounds__(256) void feed_token_ids_kernel(int64_t* __restrict__ input_ids, const int32_t* __restrict__ dst,
+                                                             const int64_t* __restrict__ sampled, const int32_t* __restrict__ src, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) input_ids[dst[i]] = sampled[src[i]];
+}
+
+extern "C" int32_t nvh_feed_token_ids(int64_t* input_ids, const int32_t* dst_index, const int64_t* sampled, const int32_t* src_index,
+                                      int64_t count, nvh_stream_t stream) {
+    NVH_REQUIRE(count >= 0 && count < (1 << 30), NVH_EINVAL, "nvh_feed_token_ids: count %ld out of range", (long)count);
+    if (count == 0) return NVH_OK;
+    NVH_REQUIRE(input_ids && dst_index && sampled && src_index, NVH_EINVAL, "nvh_feed_token_ids: null pointer");
+    feed_token_ids_kernel<<<(unsigned)nvh_cdiv(count, 256), 256, 0, (hipStream_t)stream>>>(input_ids, dst_index, sampled, src_index, (int)count);
+    NVH_CHECK_LAUNCH("feed_token_ids");
+    return NVH_OK;
+}

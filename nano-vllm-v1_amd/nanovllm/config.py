@@ -1,4 +1,6 @@
-"""Engine configuration: the twelve fields (names and defaults) of the reference's config.py:53-64.
+"""Engine configuration: the twelve fields (names and defaults) of the reference's config.py:53-64, plus
+``async_scheduling`` (not in the reference; off by default): the engine schedules and launches step n+1 before it has
+read step n's sampled ids, so the GPU never waits for the host between steps.
 
 ``model`` is a local directory holding a Hugging Face ``config.json`` (and optionally
 ``*.safetensors`` weights; without them the runner initialises synthetic weights).
@@ -44,12 +46,15 @@ class Config:
     kvcache_block_size: int = 256
     num_kvcache_blocks: int = -1
     chunked_prefill: bool = False
+    async_scheduling: bool = False
 
     def __post_init__(self):
         # the reference asserts a multiple of 256 (config.py:82) but its Sequence.block_size is the constant 256
         # (engine/sequence.py:73) and every kernel here indexes 256-token pages: any other size would read wrong keys
         assert self.kvcache_block_size == 256, "the KV page is 256 tokens (kvcache_block_size must stay 256)"
         assert 1 <= self.tensor_parallel_size <= 8
+        # one step ahead, a step's input ids come from the previous sampler output ON THE DEVICE; only rank 0 samples
+        assert not (self.async_scheduling and self.tensor_parallel_size > 1), "async_scheduling needs tensor_parallel_size == 1"
         if self.hf_config is None:
             self.hf_config = load_hf_config(self.model)
         self.max_model_len = min(self.max_model_len, self.hf_config.max_position_embeddings)

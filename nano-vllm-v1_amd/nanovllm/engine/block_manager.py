@@ -20,7 +20,7 @@ from __future__ import annotations
 import numpy as np
 import xxhash
 
-from .sequence import Sequence
+from .sequence import PLACEHOLDER, Sequence
 
 NO_HASH = -1
 
@@ -69,6 +69,9 @@ class BlockManager:
         self.hash_to_block_id: dict[int, int] = {}
         self.free_block_ids = _FreeList(range(num_blocks))
         self.used_block_ids: set[int] = set()
+        # pages that filled up with a token whose id is still on the GPU (seq_id -> (sequence, page index)): they are
+        # hashed by label_deferred() once the id is known
+        self.deferred: dict[int, tuple[Sequence, int]] = {}
 
     # ------------------------------------------------------------------ hashing
     @classmethod
@@ -163,6 +166,7 @@ class BlockManager:
             seq.block_table.append(block.block_id)
 
     def deallocate(self, seq: Sequence):
+        self.deferred.pop(seq.seq_id, None)
         for page in reversed(seq.block_table):
             block = self.blocks[page]
             block.ref_count -= 1
@@ -194,5 +198,21 @@ class BlockManager:
                 block = self._take(self.free_block_ids[0])
                 seq.block_table.append(block.block_id)
             if len(tokens) == bs:
+                if tokens[-1] == PLACEHOLDER:
+                    self.deferred[seq.seq_id] = (seq, index)     # hashed when the id arrives
+                    continue
                 prefix = self.blocks[seq.block_table[index - 1]].hash if index else NO_HASH
                 self._label(block, self.compute_hash(tokens, prefix), tokens)
+
+    def label_deferred(self, seq: Sequence):
+        """Hash the page of `seq` that filled up while its last token id was unknown (call once the id is in)."""
+        entry = self.deferred.pop(seq.seq_id, None)
+        if entry is None:
+            return
+        _, index = entry
+        tokens = seq.block(index)
+        assert len(tokens) == self.block_size and PLACEHOLDER not in tokens[-2:]
+        block = self.blocks[seq.block_table[index]]
+        prefix = self.blocks[seq.block_table[index - 1]].hash if index else NO_HASH
+        if block.hash == NO_HASH:
+            self._label(block, self.compute_hash(tokens, prefix), tokens)

@@ -53,6 +53,7 @@ class LLMEngine:
             eos = getattr(config.hf_config, "eos_token_id", -1)
             config.eos = eos[0] if isinstance(eos, (list, tuple)) else (-1 if eos is None else eos)
         self.scheduler = Scheduler(config)
+        self._inflight = None                   # async_scheduling: (placeholders, ids on their way) of the step last launched
         self._closed = False
         atexit.register(self.exit)
 
@@ -73,6 +74,8 @@ class LLMEngine:
         self.scheduler.add(Sequence(prompt, sampling_params))
 
     def step(self):
+        if self.config.async_scheduling:
+            return self._step_ahead()
         seqs = self.scheduler.schedule()
         token_ids, need = self.model_runner.call("run", seqs)
         self.scheduler.postprocess(seqs, token_ids, need.tolist())
@@ -80,8 +83,27 @@ class LLMEngine:
         num_total_tokens = sum(len(seq) for seq in seqs if seq.is_finished)
         return outputs, num_total_tokens
 
+    def _step_ahead(self):
+        """One step of the engine running one step ahead of its results (Config.async_scheduling; the reference's loop,
+        engine/llm_engine.py:117-126, is the synchronous branch above): schedule and launch the next step from what is
+        known without the ids still on the GPU - lengths, pages, budgets; the ids themselves are fed to it on the
+        device - and only then wait for the previous step's ids, while the GPU is busy.  What the reference decides
+        from an id's VALUE (eos) is decided one step later; the one token computed past an eos is dropped."""
+        launched = None
+        if not self.scheduler.is_finished():
+            seqs = self.scheduler.schedule()
+            tokens = self.model_runner.run_async(seqs)
+            launched = (self.scheduler.advance(seqs, tokens.need), tokens)
+        done = []
+        if self._inflight is not None:
+            pending, tokens = self._inflight
+            done = self.scheduler.commit(pending, tokens.result())
+        self._inflight = launched
+        outputs = [(seq.seq_id, seq.completion_token_ids) for seq in done]
+        return outputs, sum(len(seq) for seq in done)
+
     def is_finished(self) -> bool:
-        return self.scheduler.is_finished()
+        return self.scheduler.is_finished() and self._inflight is None
 
     def generate(self, prompts: list[str] | list[list[int]], sampling_params: SamplingParams | list[SamplingParams],
                  use_tqdm: bool = True) -> list[dict]:

@@ -135,6 +135,19 @@ class _Staging:
 _TORCH_DTYPE = {np.int64: torch.int64, np.int32: torch.int32, np.float32: torch.float32}
 
 
+class PendingTokens:
+    """Sampled ids of a launched step on their way to the host (ModelRunner.run_async)."""
+
+    def __init__(self, buf, event, need: list[int], count: int):
+        self.buf, self.event, self.need, self.count = buf, event, need, count
+
+    def result(self) -> list[int]:
+        if self.count == 0:
+            return []
+        self.event.synchronize()
+        return self.buf[:self.count].tolist()
+
+
 class ModelRunner:
     def __init__(self, config: Config, rank: int, event):
         self.config = config
@@ -146,6 +159,8 @@ class ModelRunner:
         self.event = event
         self.external_group = dist.is_initialized()
         self.shm = None
+        self.prev_sampled = None                # run_async: the last sampler output, kept on the device for the next step
+        self._token_bufs, self._token_flip = [None, None], 0    # pinned landing buffers of two steps in flight
 
         # NANOVLLM_SHARE_DEVICE=1: every rank on device 0 with gloo as the control plane (rehearsal on a one-GPU box)
         share_device = os.environ.get("NANOVLLM_SHARE_DEVICE", "0") == "1"
@@ -364,7 +379,12 @@ class ModelRunner:
             if self.decode_plan(rows, int(lens.max()))[1]:
                 plan = ops.plan_decode_items(lens, max_ranges=self.MAX_RANGES)
                 arrays.update({k: plan[k] for k in ("item_seq", "item_range", "seq_active", "seq_chunk")})
+        fed = fb.get("fed")
+        if fed is not None:
+            arrays["fed_dst"], arrays["fed_src"] = fed
         d = self.staging.upload(arrays)
+        if fed is not None:
+            ops.feed_token_ids(d["input_ids"], d["fed_dst"], self.prev_sampled, d["fed_src"])
         fb["items"] = None if plan is None else {k: d[k] for k in ("item_seq", "item_range", "seq_active", "seq_chunk")}
         fb["tails"] = (d.get("cu_seqlens_q_tail"), d.get("cu_seqlens_k_tail"))
         set_context(d["cu_seqlens_q"], d["cu_seqlens_k"], fb["max_seqlen_q"], fb["max_seqlen_k"], d["slot_mapping"],
@@ -464,12 +484,13 @@ class ModelRunner:
         with ``need`` a HOST int32 tensor (indices into ``seqs`` of the rows of ``logits``).  logits is
         None on ranks > 0 and when no sequence finishes its scheduled prompt in this step."""
         fb = flatten_batch(seqs, self.block_size)
+        fb["fed"] = self._fed_indices(seqs, fb)
         graph = self._graph_for(fb)
         need_host = torch.from_numpy(fb["need"])
         has_tables = any(len(s.block_table) for s in seqs)
         skip_logits = fb["need"].size == 0 and has_tables
         if graph is not None:
-            hidden, temps = graph.replay(fb, seqs, self.rank == 0)
+            hidden, temps = graph.replay(fb, seqs, self.rank == 0, self.prev_sampled)
             rows = hidden[:len(seqs)]
             logits = self.native.logits(rows) if self.native is not None else self.model.lm_head.forward_rows(rows)
         else:
@@ -497,6 +518,39 @@ class ModelRunner:
             self.comm.check()                   # a step this slow may have sat through an exchange timeout: raise, do not go on
         return token_ids, need_host
 
+    def _fed_indices(self, seqs, fb):
+        """(positions in the flat input_ids, rows of the previous step's sampler output) of the tokens whose ids have
+        not been read back yet - placeholders left by an engine that runs one step ahead - or None."""
+        dst = np.flatnonzero(fb["input_ids"] < 0).astype(np.int32)
+        if dst.size == 0:
+            return None
+        assert self.prev_sampled is not None and self.world_size == 1
+        owner = np.searchsorted(fb["cu_seqlens_q"][1:], dst, side="right")
+        src = np.fromiter((seqs[int(i)].pending_slot for i in owner), dtype=np.int32, count=dst.size)
+        assert src.min() >= 0 and src.max() < self.prev_sampled.numel()
+        return dst, src
+
+    @torch.inference_mode()
+    def run_async(self, seqs) -> "PendingTokens":
+        """`run()` without the wait: the step is launched, the sampled ids start their way to a pinned host buffer and
+        stay on the device for the next step (whose placeholder input ids are filled from them there); the caller reads
+        them with `.result()` when it needs them - normally after it has launched the next step."""
+        logits, temps, need_host = self.forward_logits(seqs)
+        need = need_host.tolist()
+        if logits is None:
+            return PendingTokens(None, None, need, 0)
+        sampled = self.sampler(logits, temps)
+        n = sampled.numel()
+        self._token_flip ^= 1
+        buf = self._token_bufs[self._token_flip]
+        if buf is None or buf.numel() < n:
+            buf = self._token_bufs[self._token_flip] = torch.empty(max(n, 1024), dtype=torch.int64, device="cpu", pin_memory=True)
+        buf[:n].copy_(sampled, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self.prev_sampled = sampled
+        return PendingTokens(buf, event, need, n)
+
     # -------------------------------------------------------------- hipGraph decode
     @torch.inference_mode()
     def capture_graphs(self):
@@ -522,7 +576,7 @@ class _DecodeGraph:
         self.items_cap = bs + runner.ITEM_SLACK
         sizes = dict(input_ids=bs * 8, positions=bs * 8, slot_mapping=bs * 4, context_lens=bs * 4,
                      block_tables=bs * width * 4, temperatures=bs * 4, item_seq=self.items_cap * 4,
-                     item_range=self.items_cap * 4, seq_active=bs * 4, seq_chunk=bs * 4)
+                     item_range=self.items_cap * 4, seq_active=bs * 4, seq_chunk=bs * 4, fed_dst=bs * 4, fed_src=bs * 4)
         self.offs, n = {}, 0
         for name, nbytes in sizes.items():
             self.offs[name] = (n, nbytes)
@@ -582,9 +636,10 @@ class _DecodeGraph:
                     slot_mapping=v("slot_mapping", torch.int32, bs), context_lens=v("context_lens", torch.int32, bs),
                     block_tables=v("block_tables", torch.int32, bs, w), temperatures=v("temperatures", torch.float32, bs),
                     item_seq=v("item_seq", torch.int32, self.items_cap), item_range=v("item_range", torch.int32, self.items_cap),
-                    seq_active=v("seq_active", torch.int32, bs), seq_chunk=v("seq_chunk", torch.int32, bs))
+                    seq_active=v("seq_active", torch.int32, bs), seq_chunk=v("seq_chunk", torch.int32, bs),
+                    fed_dst=v("fed_dst", torch.int32, bs), fed_src=v("fed_src", torch.int32, bs))
 
-    def replay(self, fb, seqs, want_temps: bool):
+    def replay(self, fb, seqs, want_temps: bool, prev_sampled=None):
         n = len(seqs)
         if not self.event.query():              # the previous step's copy has left the pinned buffer (almost always: the
             self.event.synchronize()            # caller read that step's ids back since)
@@ -602,8 +657,14 @@ class _DecodeGraph:
         long = self.graph_long is not None and self.runner.decode_plan(n, fb["max_seqlen_k"])[1]
         if long:
             self._plan_items()
+        fed = fb.get("fed")
+        if fed is not None:
+            k = fed[0].size
+            h["fed_dst"][:k], h["fed_src"][:k] = fed
         self.dev.copy_(self.host, non_blocking=True)
         self.event.record()
+        if fed is not None:                     # ids that are still on the GPU: from the previous sampler output
+            ops.feed_token_ids(self.d["input_ids"], self.d["fed_dst"][:k], prev_sampled, self.d["fed_src"][:k])
         temps = self.d["temperatures"][:n] if want_temps else None
         if long:
             self.graph_long.replay()

@@ -6,6 +6,13 @@ What the runner sees of a scheduled sequence is (num_cached_tokens, num_new_toke
 simply num_new_tokens == 1.  `schedule()` returns the list (running sequences first, newly admitted after);
 `postprocess()` consumes the sampled ids, which exist only for the sequences whose scheduled tokens reach the
 end of what they hold (`seq_need_compute_logits` indexes into the scheduled list).
+
+An engine that runs one step ahead (Config.async_scheduling; not in the reference) splits `postprocess()` in two:
+`advance()` right after a step is launched - everything that depends on LENGTHS only, with a placeholder for each
+token still to come - and `commit()` once the ids have been read back, one step later: it fills the placeholders
+in, ends the sequences that drew eos (the step launched in between computed one token too many for them, which is
+dropped) and hashes the pages that filled up meanwhile.  The sequences end with the same tokens as under
+`postprocess()`.
 """
 from __future__ import annotations
 
@@ -13,7 +20,7 @@ from collections import deque
 
 from ..config import Config
 from .block_manager import BlockManager
-from .sequence import Sequence, SequenceStatus
+from .sequence import PLACEHOLDER, Sequence, SequenceStatus
 
 
 class Scheduler:
@@ -126,3 +133,56 @@ class Scheduler:
             if seq.status != SequenceStatus.FINISHED:
                 seq.num_cached_tokens += seq.num_new_tokens
                 seq.num_new_tokens = 0
+
+    # ------------------------------------------------------------------ one step ahead
+    def advance(self, seqs: list[Sequence], seq_need_compute_logits) -> list[tuple[Sequence, int]]:
+        """Bookkeeping of a step that has been launched but whose sampled ids are still on the GPU.  Returns, per
+        entry of the need list, (sequence, index of its placeholder): what `commit()` will fill in."""
+        pending = []
+        for row, index in enumerate(int(i) for i in seq_need_compute_logits):
+            seq = seqs[index]
+            seq.append_token(PLACEHOLDER)
+            seq.pending_slot = row
+            pending.append((seq, len(seq) - 1))
+            if seq.num_completion_tokens == seq.max_tokens or len(seq) >= self.max_model_len:
+                # ends here whatever the id turns out to be; its pages go back now (a step launched later cannot
+                # overtake this one on the GPU)
+                seq.status = SequenceStatus.FINISHED
+                self.block_manager.deallocate(seq)
+                self.running.remove(seq)
+        for seq in seqs:
+            if seq.status != SequenceStatus.FINISHED:
+                seq.num_cached_tokens += seq.num_new_tokens
+                seq.num_new_tokens = 0
+        return pending
+
+    def commit(self, pending: list[tuple[Sequence, int]], token_ids: list[int]) -> list[Sequence]:
+        """The ids of an `advance()`d step have arrived.  Returns the sequences that are finished with every id known."""
+        assert len(pending) == len(token_ids)
+        done = []
+        for (seq, pos), token_id in zip(pending, token_ids):
+            if pos >= len(seq):
+                continue                        # drew eos one step earlier: this is the token computed past its end
+            assert seq.token_ids[pos] == PLACEHOLDER
+            seq.token_ids[pos] = token_id
+            hit_eos = not seq.ignore_eos and token_id == self.eos
+            if hit_eos:
+                # a step launched meanwhile fed eos back in and sampled once more: that token is dropped
+                del seq.token_ids[pos + 1:]
+                seq.num_tokens = pos + 1
+            if pos == len(seq) - 1:
+                seq.last_token = token_id
+            if seq.status == SequenceStatus.FINISHED:       # ended by length in advance(), in this step or the next
+                if pos == len(seq) - 1:
+                    done.append(seq)
+            elif hit_eos:
+                if seq.status == SequenceStatus.RUNNING:
+                    self.running.remove(seq)
+                else:
+                    self.waiting.remove(seq)    # pre-empted in the step between
+                seq.status = SequenceStatus.FINISHED
+                self.block_manager.deallocate(seq)
+                done.append(seq)
+            elif seq.status == SequenceStatus.RUNNING:
+                self.block_manager.label_deferred(seq)
+        return done

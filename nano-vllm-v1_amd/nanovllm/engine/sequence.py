@@ -10,6 +10,9 @@ from itertools import count
 from ..sampling_params import SamplingParams
 
 
+PLACEHOLDER = -1     # a sampled token whose id has not been read back yet (engine steps that run one step ahead)
+
+
 class SequenceStatus(Enum):
     WAITING = auto()
     RUNNING = auto()
@@ -34,6 +37,7 @@ class Sequence:
         self.temperature = sp.temperature
         self.max_tokens = sp.max_tokens
         self.ignore_eos = sp.ignore_eos
+        self.pending_slot = -1              # row of the newest placeholder's id in the sampler output it will come from
 
     def __len__(self):
         return self.num_tokens

@@ -110,7 +110,10 @@ class NativeQwen3:
     def forward(self, input_ids, positions, *, mode, batch, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0,
                 max_seqlen_k=0, slot_mapping=None, context_lens=None, block_tables=None, decode_splits=1,
                 decode_prefix=0, cu_seqlens_q_tail=None, cu_seqlens_k_tail=None, decode_min_range=0,
-                decode_items=None):
+                decode_items=None, out=None, workspace=None):
+        """One step: final-norm hidden states [T, hidden].  `out` / `workspace` (uint8, at least workspace_bytes()):
+        buffers of the caller's instead of fresh ones - a capture that runs two steps side by side on two streams
+        allocates them beforehand."""
         t = input_ids.numel()
         st = StepDesc()
         st.num_tokens, st.batch = t, batch
@@ -129,8 +132,11 @@ class NativeQwen3:
             st.decode_prefix = decode_prefix
             st.cu_seqlens_q_tail, st.cu_seqlens_k_tail = _ptr(cu_seqlens_q_tail), _ptr(cu_seqlens_k_tail)
         nbytes = self.lib.nvh_qwen3_workspace_bytes(C.byref(self.desc), t, batch, st.decode_splits)
-        ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
-        out = torch.empty(t, self.desc.hidden, dtype=torch.bfloat16, device=self.device)
+        ws = workspace if workspace is not None else torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        assert ws.numel() >= nbytes
+        if out is None:
+            out = torch.empty(t, self.desc.hidden, dtype=torch.bfloat16, device=self.device)
+        assert out.shape == (t, self.desc.hidden) and out.is_contiguous()
         stream = torch.cuda.current_stream().cuda_stream
         if self.reduce_fn is None:
             _hip.check(self.lib.nvh_qwen3_forward(C.byref(self.desc), C.byref(st), out.data_ptr(), ws.data_ptr(), nbytes, stream),
@@ -149,6 +155,9 @@ class NativeQwen3:
             if part < last:
                 self.reduce_fn(sums[0] if part == 0 else sums[1])
         return out
+
+    def workspace_bytes(self, num_tokens: int, batch: int, decode_splits: int) -> int:
+        return max(16, self.lib.nvh_qwen3_workspace_bytes(C.byref(self.desc), num_tokens, batch, max(1, decode_splits)))
 
     def logits(self, hidden, cu_seqlens_q=None, need=None, num_rows=None):
         """lm_head over the last scheduled row of the selected sequences (cu_seqlens_q None: `hidden`

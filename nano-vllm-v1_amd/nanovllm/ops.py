@@ -139,6 +139,16 @@ def embedding(ids: torch.Tensor, table: torch.Tensor, vocab_start: int = 0) -> t
     return out
 
 
+def feed_token_ids(input_ids: torch.Tensor, dst_index: torch.Tensor, sampled: torch.Tensor, src_index: torch.Tensor) -> None:
+    """input_ids[dst_index[i]] = sampled[src_index[i]], in place (ids a step takes from the previous step's sampler
+    output before the host has read them)."""
+    assert input_ids.dtype == torch.int64 and sampled.dtype == torch.int64 and input_ids.is_cuda and sampled.is_cuda
+    assert dst_index.dtype == torch.int32 and src_index.dtype == torch.int32 and dst_index.numel() == src_index.numel()
+    assert input_ids.is_contiguous() and sampled.is_contiguous()
+    _hip.call("nvh_feed_token_ids", input_ids.data_ptr(), dst_index.data_ptr(), sampled.data_ptr(), src_index.data_ptr(),
+              dst_index.numel(), _stream())
+
+
 def gather_last_rows(hidden: torch.Tensor, cu_seqlens_q: torch.Tensor, need: torch.Tensor | None, num_rows: int) -> torch.Tensor:
     _gpu_bf16(hidden)
     assert hidden.is_contiguous() and cu_seqlens_q.dtype == torch.int32

@@ -74,9 +74,9 @@ def serve(engine, prompts, sampling_params, arrival_offsets, progress=None):
             continue
         finished, _ = engine.step()
         now = time.perf_counter()
-        for seq in engine.scheduler.running:           # prompt fully computed => its first token was just sampled
+        for seq in engine.scheduler.running:           # its first generated id has reached the host
             c = clocks.get(seq.seq_id)
-            if c is not None and seq.num_cached_tokens >= seq.num_prompt_tokens:
+            if c is not None and math.isnan(c.first_token) and len(seq) > seq.num_prompt_tokens and seq[seq.num_prompt_tokens] >= 0:
                 c.saw_token(now)
         for seq_id, ids in finished:
             if seq_id in clocks:
@@ -111,6 +111,7 @@ def main(argv=None):
     ap.add_argument("--random-output-len", type=int, default=128)
     ap.add_argument("--chunked-prefill", action="store_true")
     ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--async-scheduling", action="store_true", help="the engine launches step n+1 before it reads step n's ids")
     ap.add_argument("--num-kvcache-blocks", type=int, default=-1, help="KV pages (default: from free memory)")
     ap.add_argument("--warmup-requests", type=int, default=50)
     args = ap.parse_args(argv)
@@ -123,7 +124,7 @@ def main(argv=None):
     llm = LLM(args.model, enforce_eager=args.enforce_eager, max_model_len=args.max_model_len,
               max_num_batched_tokens=args.max_num_batched_tokens, max_num_seqs=args.max_num_seqs,
               tensor_parallel_size=args.tensor_parallel_size, chunked_prefill=args.chunked_prefill,
-              num_kvcache_blocks=args.num_kvcache_blocks)
+              num_kvcache_blocks=args.num_kvcache_blocks, async_scheduling=args.async_scheduling)
 
     def batch(n):
         return ([[randint(0, 10000) for _ in range(args.random_input_len)] for _ in range(n)],

@@ -193,3 +193,56 @@ def test_generate_uneven_contexts_over_the_work_list(weights, monkeypatch):
         assert llm.is_finished() and not llm.scheduler.block_manager.used_block_ids
     finally:
         llm.exit()
+
+
+def test_one_step_ahead_engine_draws_the_tokens_of_the_synchronous_engine(weights):
+    """Config.async_scheduling launches step n+1 before it reads step n's ids (they are fed to it on the device).  With
+    every request present from the start and no eos, both engines run the same batches, so even the sampler's noise
+    is the same: identical ids at temperature 0.8, through chunked prefill, mixed steps and decode graphs."""
+    from nanovllm import SamplingParams
+    prompts = prompts_of([5, 300, 257, 64, 700, 31], seed=11)
+    sps = [SamplingParams(temperature=0.8, max_tokens=n, ignore_eos=True) for n in (40, 4, 9, 300, 5, 1)]
+    outs = []
+    for ahead in (False, True):
+        llm = make_llm(weights, max_num_batched_tokens=200, async_scheduling=ahead)
+        try:
+            outs.append([o["token_ids"] for o in llm.generate(prompts, sps, use_tqdm=False)])
+            assert llm.is_finished() and not llm.scheduler.block_manager.used_block_ids
+        finally:
+            llm.exit()
+    assert [len(t) for t in outs[0]] == [40, 4, 9, 300, 5, 1]
+    assert outs[1] == outs[0]
+
+
+def test_one_step_ahead_engine_ends_at_eos_and_survives_preemption(weights):
+    """eos is seen one step late when the engine runs ahead: the token computed past it must be dropped, the
+    pages released, and every id must still be the oracle's argmax at its position (near-greedy temperature)."""
+    from nanovllm import SamplingParams
+    prompts = prompts_of([250, 252, 255, 40, 9], seed=12)
+    sp = SamplingParams(temperature=1e-9, max_tokens=40, ignore_eos=True)
+    llm = make_llm(weights, num_kvcache_blocks=4, max_num_batched_tokens=1024)
+    try:
+        free_run = [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
+    finally:
+        llm.exit()
+    # an id that occurs mid-way in several of the free-running completions becomes eos
+    counts = {}
+    for ids in free_run:
+        for t in set(ids[3:30]):
+            counts[t] = counts.get(t, 0) + 1
+    eos = max(counts, key=counts.get)
+    want = [ids[:ids.index(eos) + 1] if eos in ids else ids for ids in free_run]
+    assert sum(len(w) < 40 for w in want) >= 1
+    llm = make_llm(weights, num_kvcache_blocks=4, max_num_batched_tokens=1024, async_scheduling=True)
+    try:
+        llm.scheduler.eos = eos
+        sp = SamplingParams(temperature=1e-9, max_tokens=40, ignore_eos=False)
+        got = [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
+        assert llm.scheduler.num_preemptions > 0
+        assert llm.is_finished() and not llm.scheduler.block_manager.used_block_ids and not llm.scheduler.block_manager.deferred
+    finally:
+        llm.exit()
+    for p, ids, w in zip(prompts, got, want):
+        assert -1 not in ids and (eos not in ids[:-1]) and (ids[-1] == eos or len(ids) == 40)
+        check_teacher_forced(weights, p, ids)
+    assert sum(g == w for g, w in zip(got, want)) >= len(want) - 1          # at most one bf16 tie resolved the other way
