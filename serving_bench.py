@@ -148,7 +148,7 @@ def main(argv=None):
     print("-------------------------\n")
     r["config"] = {k: getattr(args, k) for k in ("model", "num_requests", "request_rate", "max_num_batched_tokens", "max_num_seqs",
                                                   "tensor_parallel_size", "random_input_len", "random_output_len",
-                                                  "chunked_prefill", "enforce_eager")}
+                                                  "chunked_prefill", "enforce_eager", "async_scheduling")}
     print(json.dumps(r))
     llm.exit()
     return r
