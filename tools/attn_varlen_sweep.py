@@ -2,7 +2,7 @@
 """Var-len attention timing over the prefill shapes of a 1024-token chunk (16 q heads / 8 kv heads):
 time per launch and TFLOP/s for a list of (Lq, Lk, batch, splits) cases.  Every launch reads another
 layer's cache (28 copies), as consecutive layers of a step do.
-usage: attn_varlen_sweep.py [hq=16] [hkv=8]      env NVH_ATTN_KS=1|2 forces the key-group count"""
+usage: attn_varlen_sweep.py [hq=16] [hkv=8] [Lq:Lk:B:splits,...]      env NVH_ATTN_KS=1|2 forces the key-group count"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -15,7 +15,8 @@ hq = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 hkv = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 d, BF, L = 128, torch.bfloat16, 8
 print(f"{'Lq':>6} {'Lk':>6} {'B':>3} {'splits':>6} {'us':>9} {'TFLOP/s':>8}")
-for lq, lk, b, splits in [(1024, 1024, 1, 1), (1024, 1024, 1, 2), (1024, 1024, 1, 4), (1024, 2048, 1, 1), (1024, 2048, 1, 2),
+CASES = [tuple(int(v) for v in c.split(":")) for c in sys.argv[3].split(",")] if len(sys.argv) > 3 else None
+for lq, lk, b, splits in CASES or [(1024, 1024, 1, 1), (1024, 1024, 1, 2), (1024, 1024, 1, 4), (1024, 2048, 1, 1), (1024, 2048, 1, 2),
                           (1024, 4096, 1, 1), (1024, 4096, 1, 2), (1024, 8192, 1, 1), (1024, 8192, 1, 2), (1024, 8192, 1, 4),
                           (128, 128, 8, 1), (512, 512, 2, 1), (64, 8192, 1, 0), (16, 4096, 4, 0)]:
     pages = (lk + 255) // 256

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Cut the last decode step out of a rocprofv3 kernel trace (CSV) and print per-kernel totals.
-usage: step_breakdown.py <kernel_trace.csv>"""
+usage: step_breakdown.py <kernel_trace.csv> [kernel name part the step must contain]"""
 import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if ('sample_final_kernel' in r['Kernel_Name'] or 'sample_kernel' in r['Kernel_Name'])]
-a, b = idx[-2], idx[-1]
+want = sys.argv[2] if len(sys.argv) > 2 else None
+pairs = [(a, b) for a, b in zip(idx, idx[1:]) if b - a > 50 and (want is None or any(want in r['Kernel_Name'] for r in rows[a + 1:b + 1]))]
+a, b = pairs[-1]
 step = rows[a + 1:b + 1]
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 prev_end = int(rows[a]['End_Timestamp'])
