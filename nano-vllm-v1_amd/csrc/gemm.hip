@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split,
     QkvEpilogue qe, bool wide_store) {
     constexpr int NW = WAVES_N * WAVES_M;                 // waves per workgroup (4; 2 for the skinny decode tiles)
-    static_assert(NW == 4 || NW == 2, "2 or 4 waves");
+    static_assert(NW == 8 || NW == 4 || NW == 2, "2, 4 or 8 waves");
     constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
     constexpr int TN = WN / 16, TM = WM / 16;             // 16x16 MFMA tiles per wave
     static_assert(TN >= 1 && TM >= 1, "wave tile");
@@ -122,6 +122,67 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (NW == 8) {
+        // Eight waves, two per SIMD.  Every wave runs the same four phases per k-tile, a barrier before each:
+        //   READ k0 (12 fragment reads) | MFMA k0 (32) | READ k1 | MFMA k1
+        // and waves 4-7 run ONE barrier behind waves 0-3 (an extra barrier before their loop, one after the others'),
+        // so on every SIMD one wave issues MFMAs while the other reads LDS.  Barrier n of the workgroup is phase
+        // n mod 4 of tile n / 4 for the first half and phase (n - 1) mod 4 for the second.  Hence:
+        //  * a wave waits for its DMA pieces of tile t+1 before its 4th barrier of tile t: by the time the first half
+        //    passes its 1st barrier of tile t+1 (the same barrier for the second half) every piece has landed;
+        //  * the DMA of tile t+1 (two LDS stages: the buffer of tile t-1) is issued after the 1st barrier of tile t;
+        //    the last readers of tile t-1 are the second half's READ k1, drained (lgkmcnt) before that very barrier.
+        static_assert(STAGES == 2, "two stages with the eight-wave loop");
+        const bool second_half = wave >= 4;              // wave-uniform
+        bf16x8 af[TN], bfr[TM];
+        auto read_frags = [&](const char* a_base, int ks) {
+            const char* b_base = a_base + A_BYTES;
+            const int kc = ks * 4 + fq;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * WM + j * 16 + fr;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * WN + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(a_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+        };
+        auto mfmas = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto phase_barrier = [&]() {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::: "memory");
+        };
+        if (ntiles > 0) stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (second_half) phase_barrier();
+        for (int t = 0; t < ntiles; ++t) {
+            const char* base = smem + (t & 1) * STAGE_BYTES;
+            phase_barrier();
+            if (t + 1 < ntiles) stage(t + 1);
+            read_frags(base, 0);
+            phase_barrier();
+            mfmas();
+            phase_barrier();
+            read_frags(base, 1);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // own pieces of tile t+1; this tile's reads
+            __builtin_amdgcn_sched_barrier(0);
+            phase_barrier();
+            mfmas();
+        }
+        if (!second_half) phase_barrier();
+    } else {
     for (int t = 0; t < AHEAD && t < ntiles; ++t) stage(t);
     for (int t = 0; t < ntiles; ++t) {
         // tiles t+1 .. min(t+AHEAD-1, ntiles-1) may stay in flight; tile t must have landed
@@ -152,6 +213,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+    }
     }
 
     // epilogue: lane holds n = n_base + fq*4 .. +3 of row m = m_base + fr
@@ -354,7 +416,7 @@ void launch_gemm(const GemmArgs& a) {
 }
 
 // Tile choice: the largest tile whose grid (x split_k) still gives every CU a workgroup.
-enum Tile { T16x32, T32x32, T16x128, T32x128, T64x128, T64x64, T128x64, T128x128, T256x128 };
+enum Tile { T16x32, T32x32, T16x128, T32x128, T64x128, T64x64, T128x64, T128x128, T256x128, T256x256 };
 Tile pick_tile(int64_t M, int64_t N, int split_k) {
     // decode batches: 128-row weight tiles leave most CUs idle unless the output is very wide; 32-row tiles in
     // two-wave workgroups (three fit a CU) keep the weight stream spread over the chip
@@ -365,18 +427,21 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     if (M <= 32) return (narrow && (split_k == 1 || m32_skinny)) ? T32x32 : T32x128;      // with split-K the 128-row tile measured faster
     auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
     static const int force = getenv("NVH_GEMM_FORCE_TILE") ? atoi(getenv("NVH_GEMM_FORCE_TILE")) : -1;   // tuning switch
-    if (force >= T16x128 && force <= T256x128) return (Tile)force;
+    if (force >= T16x128 && force <= T256x256) return (Tile)force;
     if (M <= 64) return nvh_cdiv(N, 128) * split_k >= 384 ? T64x128 : T64x64;   // 33..64 rows: enough workgroups first
     // very wide outputs with few rows (LM head at decode batch 256): all rows in one tile, so every weight row is
     // fetched once; three stages, one workgroup per CU
     static const bool no256 = getenv("NVH_GEMM_NO_256") != nullptr;
     if (!no256 && M >= 256 && M <= 512 && wgs(256, 128) >= 768) return T256x128;
+    // big products (prefill of the 14B / 32B shapes, square GEMMs from 4096 up): 256 x 256 tiles in eight-wave workgroups
+    // once they fill the chip (4096^3: 985 -> 1196 TFLOP/s; 1024 x 34816 x 5120: 705 -> 877; 128 tiles: 983 -> 710)
+    if (!no256 && split_k == 1 && wgs(256, 256) >= 240) return T256x256;
     if (wgs(128, 128) >= 200) return T128x128;
     if (wgs(128, 64) >= 200) return T128x64;
     return T64x64;
 }
-int tile_bm(Tile t) { return (t == T16x128 || t == T16x32) ? 16 : (t == T32x128 || t == T32x32) ? 32 : (t == T64x128 || t == T64x64) ? 64 : t == T256x128 ? 256 : 128; }
-int tile_bn(Tile t) { return (t == T16x32 || t == T32x32) ? 32 : (t == T64x64 || t == T128x64) ? 64 : 128; }
+int tile_bm(Tile t) { return (t == T16x128 || t == T16x32) ? 16 : (t == T32x128 || t == T32x32) ? 32 : (t == T64x128 || t == T64x64) ? 64 : (t == T256x128 || t == T256x256) ? 256 : 128; }
+int tile_bn(Tile t) { return (t == T16x32 || t == T32x32) ? 32 : (t == T64x64 || t == T128x64) ? 64 : t == T256x256 ? 256 : 128; }
 }  // namespace
 static int32_t dispatch_gemm(const GemmArgs& a);
 
@@ -390,7 +455,7 @@ int tile_residents(Tile t) {
     switch (t) {
         case T16x32: case T32x32: return 3;
         case T16x128: case T32x128: case T64x64: case T128x128: return 2;
-        default: return 1;                                     // T64x128, T128x64, T256x128
+        default: return 1;                                     // T64x128, T128x64, T256x128, T256x256
     }
 }
 // Time model of one GEMM launch with `s` K-slabs, in microseconds.  These kernels are bound by the L2 -> LDS fill
@@ -503,6 +568,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
             else launch_gemm<128, 128, 2, 2, 2>(a);
             break;
         case T256x128: launch_gemm<256, 128, 2, 2, 3>(a); break;
+        case T256x256: launch_gemm<256, 256, 2, 4, 2>(a); break;
     }
     NVH_CHECK_LAUNCH("gemm_bf16_nt");
     return NVH_OK;

@@ -249,7 +249,8 @@ def test_embedding_vocab_parallel(ops):
 GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024), (33, 1024, 3072), (64, 1024, 256),
                (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256),
                (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128),   # 256x128 LM-head tile (one / two row tiles)
-               (5, 26624, 192), (40, 4096, 1024), (64, 7168, 512)]         # 16x64 two-wave tile; 64x64 at 33..64 rows
+               (5, 26624, 192), (40, 4096, 1024), (64, 7168, 512),         # 16x64 two-wave tile; 64x64 at 33..64 rows
+               (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64)]   # 256x256 eight-wave tile (full, ragged, one k-tile)
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -273,7 +274,8 @@ def test_gemm_bias_strided_input_and_splitk(ops):
 
 
 @pytest.mark.parametrize("m,inter,k", [(1, 3072, 1024), (20, 512, 256), (256, 3072, 1024), (1024, 3072, 1024), (70, 96, 192),
-                                       (3, 13312, 128), (16, 17408, 64), (48, 3072, 256)])   # 16x64 tile (832 / 1088 narrow tiles)
+                                       (3, 13312, 128), (16, 17408, 64), (48, 3072, 256),    # 16x64 tile (832 / 1088 narrow tiles)
+                                       (1024, 8192, 256)])                                   # 256x256 eight-wave tile
 def test_gemm_swiglu_epilogue_bit_identical_to_separate_kernels(ops, m, inter, k):
     x, w = rnd(m, k, seed=m + 1), rnd(2 * inter, k, seed=k + 2, scale=0.05)
     xd, wd = dev(x), dev(w)
