@@ -429,13 +429,14 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     static const int force = getenv("NVH_GEMM_FORCE_TILE") ? atoi(getenv("NVH_GEMM_FORCE_TILE")) : -1;   // tuning switch
     if (force >= T16x128 && force <= T256x256) return (Tile)force;
     if (M <= 64) return nvh_cdiv(N, 128) * split_k >= 384 ? T64x128 : T64x64;   // 33..64 rows: enough workgroups first
-    // very wide outputs with few rows (LM head at decode batch 256): all rows in one tile, so every weight row is
-    // fetched once; three stages, one workgroup per CU
     static const bool no256 = getenv("NVH_GEMM_NO_256") != nullptr;
+    // big products (prefill of the 14B / 32B shapes, square GEMMs from 4096 up, the LM head from 256 rows): 256 x 256
+    // tiles in eight-wave workgroups once they fill the chip and few of their rows are padding (4096^3: 985 -> 1196
+    // TFLOP/s; 1024 x 34816 x 5120: 705 -> 877; LM head at 256 / 512 rows: 132 -> 118 / 244 -> 215 us; 128 tiles: 983 -> 710)
+    if (!no256 && split_k == 1 && wgs(256, 256) >= 240 && nvh_cdiv(M, 256) * 256 * 8 <= M * 9) return T256x256;
+    // very wide outputs with few rows: all rows in one tile, so every weight row is fetched once; three stages, one
+    // workgroup per CU
     if (!no256 && M >= 256 && M <= 512 && wgs(256, 128) >= 768) return T256x128;
-    // big products (prefill of the 14B / 32B shapes, square GEMMs from 4096 up): 256 x 256 tiles in eight-wave workgroups
-    // once they fill the chip (4096^3: 985 -> 1196 TFLOP/s; 1024 x 34816 x 5120: 705 -> 877; 128 tiles: 983 -> 710)
-    if (!no256 && split_k == 1 && wgs(256, 256) >= 240) return T256x256;
     if (wgs(128, 128) >= 200) return T128x128;
     if (wgs(128, 64) >= 200) return T128x64;
     return T64x64;
