@@ -246,6 +246,23 @@ def test_embedding_vocab_parallel(ops):
             assert_exact(got, R.embedding(ids, shard, vocab_start=rk * n, tp_size=ws))
 
 
+def test_feed_token_ids_copies_sampled_rows_into_the_next_input(ops):
+    """input_ids[dst[i]] = sampled[src[i]] (the ids an engine running one step ahead hands to the next step on the
+    device); untouched positions keep their value."""
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 1000, (300,), generator=g, dtype=torch.int64)
+    sampled = torch.randint(1000, 2000, (40,), generator=g, dtype=torch.int64)
+    dst = torch.randperm(300, generator=g)[:33].to(torch.int32)
+    src = torch.randint(0, 40, (33,), generator=g, dtype=torch.int32)
+    want = ids.clone()
+    want[dst.long()] = sampled[src.long()]
+    got = dev(ids)
+    ops.feed_token_ids(got, dev(dst), dev(sampled), dev(src))
+    assert torch.equal(got.cpu(), want)
+    ops.feed_token_ids(got, dev(dst[:0]), dev(sampled), dev(src[:0]))          # nothing to feed: no launch
+    assert torch.equal(got.cpu(), want)
+
+
 GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024), (33, 1024, 3072), (64, 1024, 256),
                (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256),
                (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128),   # 256x128 LM-head tile (one / two row tiles)
