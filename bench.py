@@ -116,9 +116,49 @@ class Driver:
             s.block_table.append(self.next_page)
             self.next_page += 1
 
-    def prefill(self, seqs, chunk):
-        """Chunked prefill, one sequence at a time, `chunk` tokens per step; returns seconds per chunk list."""
+    def prefill(self, seqs, chunk, ahead=False):
+        """Chunked prefill, one sequence at a time, `chunk` tokens per step; returns (seconds, tokens, cached) per chunk.
+        `ahead`: the engine loop that runs one step ahead (Config.async_scheduling) - a chunk is launched before the
+        previous one has finished, its time is the interval between the completions of consecutive chunks."""
+        from nanovllm.engine.sequence import PLACEHOLDER
         times = []
+        if ahead:
+            inflight = None
+            t_prev = None
+
+            def finish(entry):
+                nonlocal t_prev
+                tokens, s, pos, n, cached = entry
+                toks = tokens.result()                               # waits for that chunk
+                now = time.perf_counter()
+                if t_prev is not None:
+                    times.append((now - t_prev, n, cached))
+                t_prev = now
+                if toks:
+                    s.token_ids[pos] = toks[0]
+                    s.last_token = s.token_ids[-1]
+
+            for s in seqs:
+                prompt_len = len(s)
+                while s.num_cached_tokens < prompt_len:
+                    n = min(chunk, prompt_len - s.num_cached_tokens)
+                    cached = s.num_cached_tokens
+                    s.num_new_tokens = n
+                    self.grow(s, cached + n)
+                    tokens = self.runner.run_async([s])
+                    s.num_cached_tokens += n
+                    s.num_new_tokens = 0
+                    pos = -1
+                    if tokens.need:
+                        s.append_token(PLACEHOLDER)
+                        s.pending_slot = 0
+                        pos = len(s) - 1
+                    if inflight is not None:
+                        finish(inflight)
+                    inflight = (tokens, s, pos, n, cached)
+            if inflight is not None:
+                finish(inflight)
+            return times
         for s in seqs:
             prompt_len = len(s)
             while s.num_cached_tokens < prompt_len:
@@ -462,8 +502,11 @@ def main():
         return [torch.randint(0, 10000, (length,), generator=g).tolist() for _ in range(n)]
 
     # ---- prefill of the decode batch: B prompts x context tokens, one 1024-token chunk per step
+    # One rank: the engine loop that runs one step ahead of its sampled ids (Config.async_scheduling), the fastest way
+    # this engine serves; the synchronous loop of the reference is timed next to it for the decode steps.
+    ahead = not distributed and os.environ.get("NANOVLLM_BENCH_SYNC", "0") != "1"
     seqs = [driver.new_seq(p) for p in prompts(b, ctx0)]
-    ptimes = driver.prefill(seqs, 1024)
+    ptimes = driver.prefill(seqs, 1024, ahead)
     note("prefill done")
     steady = [x for x in ptimes[len(ptimes) // 4:]] or ptimes
     chunk_s = sum(x[0] for x in steady) / len(steady)
@@ -473,12 +516,10 @@ def main():
                    chunk_tokens=int(chunk_tokens), chunks_timed=len(steady),
                    roofline=dict(bound="mfma", achieved=round(chunk_flops / chunk_s / 1e12, 2), peak=MFMA_PEAK_TFLOPS,
                                  unit="TFLOP/s", frac=round(chunk_flops / chunk_s / 1e12 / MFMA_PEAK_TFLOPS, 4)),
-                   note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included")
+                   note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included"
+                        + (" (engine one step ahead: a chunk's time is the interval between consecutive completions)" if ahead else ""))
 
     # ---- the timed region: K decode steps of B sequences
-    # One rank: the engine loop that runs one step ahead of its sampled ids (Config.async_scheduling), the fastest way
-    # this engine serves a decode batch; the synchronous loop of the reference is timed right after, for comparison.
-    ahead = not distributed and os.environ.get("NANOVLLM_BENCH_SYNC", "0") != "1"
     dt = time_decode(driver, seqs, args.steps, args.warmup, distributed, ahead=ahead)
     note("decode timed")
     value = b * args.steps / dt
@@ -532,7 +573,7 @@ def main():
         # ---- long-context chunked prefill: 8192-token prompts, 8 chunks of 1024 each
         driver_pages = driver.next_page
         long_seqs = [driver.new_seq(p) for p in prompts(2, 8192)]
-        lt = driver.prefill(long_seqs, 1024)[8:]                                 # second prompt (first warms up)
+        lt = driver.prefill(long_seqs, 1024, ahead)[-8:]                         # second prompt (first warms up)
         tot_s = sum(x[0] for x in lt)
         tot_f = sum(algorithmic_flops_per_chunk(hf, x[1], x[2], world) for x in lt)
         out["prefill_8k"] = dict(tok_s=round(sum(x[1] for x in lt) / tot_s, 1), tflops=round(tot_f / tot_s / 1e12, 2),

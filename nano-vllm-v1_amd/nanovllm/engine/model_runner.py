@@ -142,10 +142,10 @@ class PendingTokens:
         self.buf, self.event, self.need, self.count = buf, event, need, count
 
     def result(self) -> list[int]:
-        if self.count == 0:
-            return []
-        self.event.synchronize()
-        return self.buf[:self.count].tolist()
+        """Waits for the step (also one that sampled nothing: the caller never runs more than a step ahead of the GPU)."""
+        if self.event is not None:
+            self.event.synchronize()
+        return self.buf[:self.count].tolist() if self.count else []
 
 
 class ModelRunner:
@@ -538,7 +538,9 @@ class ModelRunner:
         logits, temps, need_host = self.forward_logits(seqs)
         need = need_host.tolist()
         if logits is None:
-            return PendingTokens(None, None, need, 0)
+            event = torch.cuda.Event()
+            event.record()
+            return PendingTokens(None, event, need, 0)
         sampled = self.sampler(logits, temps)
         n = sampled.numel()
         self._token_flip ^= 1
