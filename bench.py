@@ -253,7 +253,7 @@ def sync_all(distributed, runner=None):
 
 def time_decode(driver, seqs, steps, warmup, distributed, ahead=False):
     """Seconds for `steps` decode steps (max over the ranks).  `ahead`: the engine loop that runs one step ahead of
-    its sampled ids (single rank only); its last step's ids are read back inside the timed region."""
+    its sampled ids; its last step's ids are read back inside the timed region."""
     for _ in range(warmup):
         driver.decode_step(seqs)
     sync_all(distributed, driver.runner)
@@ -502,9 +502,10 @@ def main():
         return [torch.randint(0, 10000, (length,), generator=g).tolist() for _ in range(n)]
 
     # ---- prefill of the decode batch: B prompts x context tokens, one 1024-token chunk per step
-    # One rank: the engine loop that runs one step ahead of its sampled ids (Config.async_scheduling), the fastest way
-    # this engine serves; the synchronous loop of the reference is timed next to it for the decode steps.
-    ahead = not distributed and os.environ.get("NANOVLLM_BENCH_SYNC", "0") != "1"
+    # The loop that runs one step ahead of its sampled ids (what Config.async_scheduling does in the engine): the fastest
+    # way this runner serves; the synchronous loop of the reference is timed next to it for the decode steps.  With
+    # several ranks every rank runs the same schedule and the ids reach all of them on the device (comm.broadcast_ids).
+    ahead = os.environ.get("NANOVLLM_BENCH_SYNC", "0") != "1"
     seqs = [driver.new_seq(p) for p in prompts(b, ctx0)]
     ptimes = driver.prefill(seqs, 1024, ahead)
     note("prefill done")
@@ -533,7 +534,7 @@ def main():
                config=dict(workload=f"{model_name} TP={world} bf16 decode, B={b} sequences x ~{ctx0} context tokens, "
                                     "chunked_prefill on, max_num_batched_tokens=1024, hipGraph decode",
                            batch=b, context=ctx0, parallelism=f"tp{world}", kv_page=PAGE,
-                           engine_loop=("one step ahead (Config.async_scheduling): step n+1 is launched before step n's ids are read back"
+                           engine_loop=("one step ahead (ModelRunner.run_async, as Config.async_scheduling uses it): step n+1 is launched before step n's ids are read back"
                                         if ahead else "synchronous (schedule, run, read ids back, postprocess)")),
                step_roofline=dict(bound="hbm", achieved=round(step_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(step_gbs / HBM_PEAK_GBS, 4), bytes_per_step=int(step_bytes),

@@ -126,6 +126,14 @@ int32_t nvh_gather_last_rows(const void* hidden, const int32_t* cu_seqlens_q, co
 int32_t nvh_feed_token_ids(int64_t* input_ids, const int32_t* dst_index, const int64_t* sampled,
                            const int32_t* src_index, int64_t count, nvh_stream_t stream);
 
+/* Token ids <-> three bf16 bytes each (enc[i], enc[count + i], enc[2 count + i]; exact in bf16), padded_count >= 3 count
+ * entries written (ids null: all zeros).  With these, rank 0's sampled ids reach every tensor-parallel rank through the
+ * SAME sum over the ranks as the activations (layers/linear.py:407-409) - the other ranks add zeros - instead of the
+ * reference's host round trip (engine/model_runner.py:602-638 returns the ids to the scheduler, which sends them back
+ * with the next step). */
+int32_t nvh_ids_to_bytes_bf16(const int64_t* ids, void* enc, int64_t count, int64_t padded_count, nvh_stream_t stream);
+int32_t nvh_bytes_bf16_to_ids(const void* enc, int64_t* ids, int64_t count, nvh_stream_t stream);
+
 /* ---- G1-G5: y[M,N] = x[M,K] @ W[N,K]^T (+ bias[N]), fp32 accumulation, bf16 out.
  * layers/linear.py:130,198,407 and layers/embed_head.py:204 (F.linear -> cuBLAS).
  * K % 64 == 0.  split_k > 1: fp32 partial slabs [split_k, M, N] are written to `workspace`

@@ -546,3 +546,34 @@ extern "C" int32_t nvh_feed_token_ids(int64_t* input_ids, const int32_t* dst_ind
     NVH_CHECK_LAUNCH("feed_token_ids");
     return NVH_OK;
 }
+
+// Token ids as three bf16 bytes each (0..255: exact), so that "rank 0's sampled ids, zeros elsewhere" can ride the same
+// sum over the ranks as the activations and every rank ends up with the ids: enc[i], enc[n + i], enc[2n + i] = byte 0, 1, 2
+// of ids[i]; ids == nullptr writes zeros.  Entries n*3 .. padded are zeroed (the exchange wants a multiple of 8).
+__global__ __launch_bounds__(256) void ids_to_bytes_kernel(const int64_t* __restrict__ ids, bf16* __restrict__ enc, int n, int padded) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= padded) return;
+    float v = 0.f;
+    if (ids != nullptr && i < 3 * n) v = (float)((ids[i % n] >> (8 * (i / n))) & 255);
+    enc[i] = f2bf(v);
+}
+__global__ __launch_bounds__(256) void bytes_to_ids_kernel(const bf16* __restrict__ enc, int64_t* __restrict__ ids, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ids[i] = (int64_t)bf2f(enc[i]) + ((int64_t)bf2f(enc[n + i]) << 8) + ((int64_t)bf2f(enc[2 * n + i]) << 16);
+}
+
+extern "C" int32_t nvh_ids_to_bytes_bf16(const int64_t* ids, void* enc, int64_t count, int64_t padded_count, nvh_stream_t stream) {
+    NVH_REQUIRE(enc && count >= 0 && padded_count >= 3 * count && padded_count < (1 << 30), NVH_EINVAL, "nvh_ids_to_bytes_bf16: bad arguments");
+    if (padded_count == 0) return NVH_OK;
+    ids_to_bytes_kernel<<<(unsigned)nvh_cdiv(padded_count, 256), 256, 0, (hipStream_t)stream>>>(ids, (bf16*)enc, (int)count, (int)padded_count);
+    NVH_CHECK_LAUNCH("ids_to_bytes");
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_bytes_bf16_to_ids(const void* enc, int64_t* ids, int64_t count, nvh_stream_t stream) {
+    NVH_REQUIRE(enc && ids && count >= 0 && count < (1 << 28), NVH_EINVAL, "nvh_bytes_bf16_to_ids: bad arguments");
+    if (count == 0) return NVH_OK;
+    bytes_to_ids_kernel<<<(unsigned)nvh_cdiv(count, 256), 256, 0, (hipStream_t)stream>>>((const bf16*)enc, ids, (int)count);
+    NVH_CHECK_LAUNCH("bytes_to_ids");
+    return NVH_OK;
+}

@@ -29,6 +29,8 @@ SIGNATURES = {
     "nvh_embedding": (i32, [vp, vp, vp, i64, i64, i64, i64, vp]),
     "nvh_gather_last_rows": (i32, [vp, vp, vp, vp, i64, i64, vp]),
     "nvh_feed_token_ids": (i32, [vp, vp, vp, vp, i64, vp]),
+    "nvh_ids_to_bytes_bf16": (i32, [vp, vp, i64, i64, vp]),
+    "nvh_bytes_bf16_to_ids": (i32, [vp, vp, i64, vp]),
     "nvh_gemm_bf16_nt": (i32, [vp, i64, vp, vp, vp, i64, i64, i64, i64, i32, vp, vp]),
     "nvh_gemm_workspace_bytes": (i64, [i64, i64, i32]),
     "nvh_gemm_suggest_split_k": (i32, [i64, i64, i64]),

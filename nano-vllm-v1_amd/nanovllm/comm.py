@@ -218,6 +218,21 @@ def gather_cols(x: torch.Tensor, root: int = 0) -> torch.Tensor | None:
     return torch.cat(parts, -1).to(x.device) if rank == root else None
 
 
+def broadcast_ids(ids: "torch.Tensor | None", count: int, device) -> torch.Tensor:
+    """Rank 0's `count` sampled ids (int64 on the device; None on the other ranks) -> the same ids on every rank, on
+    the device, without the host.  They travel as three bf16 bytes each through `all_reduce` - the very sum over the
+    ranks the activations take (peer exchange or torch.distributed), the other ranks adding zeros - so no second kind
+    of collective is involved."""
+    padded = (3 * count + 7) // 8 * 8
+    enc = torch.empty(padded, dtype=torch.bfloat16, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    _hip.call("nvh_ids_to_bytes_bf16", 0 if ids is None else ids.data_ptr(), enc.data_ptr(), count, padded, stream)
+    all_reduce(enc)
+    out = torch.empty(count, dtype=torch.int64, device=device)
+    _hip.call("nvh_bytes_bf16_to_ids", enc.data_ptr(), out.data_ptr(), count, stream)
+    return out
+
+
 def all_reduce(y: torch.Tensor) -> torch.Tensor:
     """In-place sum over the tensor-parallel ranks."""
     if _ACTIVE is not None and _ACTIVE.fits(y):

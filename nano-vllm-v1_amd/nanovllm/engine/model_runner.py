@@ -524,7 +524,7 @@ class ModelRunner:
         dst = np.flatnonzero(fb["input_ids"] < 0).astype(np.int32)
         if dst.size == 0:
             return None
-        assert self.prev_sampled is not None and self.world_size == 1
+        assert self.prev_sampled is not None
         owner = np.searchsorted(fb["cu_seqlens_q"][1:], dst, side="right")
         src = np.fromiter((seqs[int(i)].pending_slot for i in owner), dtype=np.int32, count=dst.size)
         assert src.min() >= 0 and src.max() < self.prev_sampled.numel()
@@ -534,14 +534,19 @@ class ModelRunner:
     def run_async(self, seqs) -> "PendingTokens":
         """`run()` without the wait: the step is launched, the sampled ids start their way to a pinned host buffer and
         stay on the device for the next step (whose placeholder input ids are filled from them there); the caller reads
-        them with `.result()` when it needs them - normally after it has launched the next step."""
+        them with `.result()` when it needs them - normally after it has launched the next step.  Under tensor
+        parallelism every rank calls it with the same sequences: rank 0 samples, the ids reach the other ranks on the
+        device (comm.broadcast_ids), and every rank can read them back."""
         logits, temps, need_host = self.forward_logits(seqs)
         need = need_host.tolist()
-        if logits is None:
+        count = len(need) if (need or any(len(s.block_table) for s in seqs)) else len(seqs)
+        if count == 0:
             event = torch.cuda.Event()
             event.record()
             return PendingTokens(None, event, need, 0)
-        sampled = self.sampler(logits, temps)
+        sampled = self.sampler(logits, temps) if self.rank == 0 else None
+        if self.world_size > 1:
+            sampled = comm.broadcast_ids(sampled, count, self.device)
         n = sampled.numel()
         self._token_flip ^= 1
         buf = self._token_bufs[self._token_flip]

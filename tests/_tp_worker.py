@@ -60,6 +60,40 @@ def rccl_capture_check(port):
     print("rank 0 OK")
 
 
+def check_one_step_ahead(runner, seqs, tables, rank, world):
+    """Two steps launched back to back with run_async on every rank: the second takes its input ids from the first
+    one's sampler output on the device (rank 0 samples; the ids reach the other ranks through the exchange).  Every
+    rank must read back the same ids, and the second step's ids must be what a synchronous step computes from the
+    first step's ids (near-greedy temperature)."""
+    from nanovllm.engine.sequence import PLACEHOLDER
+    for s in seqs:
+        s.temperature = 1e-9
+
+    def advance(first):
+        for i, s in enumerate(seqs):
+            s.num_cached_tokens += s.num_new_tokens
+            s.append_token(PLACEHOLDER)
+            s.pending_slot = i
+            s.num_new_tokens = 1
+            s.block_table = tables[i][:(len(s) + 255) // 256]
+
+    p1 = runner.run_async(seqs)
+    advance(True)
+    p2 = runner.run_async(seqs)                      # input ids: placeholders, fed from p1's ids on the device
+    ids1, ids2 = p1.result(), p2.result()
+    assert len(ids1) == len(ids2) == len(seqs)
+    both = torch.tensor(ids1 + ids2, dtype=torch.int64)
+    gathered = [torch.empty_like(both) for _ in range(world)]
+    dist.all_gather(gathered, both)
+    assert all(torch.equal(g, both) for g in gathered), "the ranks read back different ids"
+    for s, t in zip(seqs, ids1):
+        s.token_ids[-1] = t
+        s.last_token = t
+    logits, _, _ = runner.forward_logits(seqs)       # the second step again, synchronously, from the real ids
+    if rank == 0:
+        assert logits.float().argmax(-1).tolist() == ids2, "the step launched ahead did not see the previous step's ids"
+
+
 def main():
     rank, world, port, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     if mode == "rccl1":
@@ -131,6 +165,8 @@ def main():
     else:
         tok, need = runner.run(seqs)
         assert tok is None
+    if mode in ("native", "graph", "fallback"):
+        check_one_step_ahead(runner, seqs, tables, rank, world)
     runner.exit()
     dist.destroy_process_group()
     print(f"rank {rank} OK")
