@@ -53,8 +53,6 @@ class Config:
         # (engine/sequence.py:73) and every kernel here indexes 256-token pages: any other size would read wrong keys
         assert self.kvcache_block_size == 256, "the KV page is 256 tokens (kvcache_block_size must stay 256)"
         assert 1 <= self.tensor_parallel_size <= 8
-        # one step ahead, a step's input ids come from the previous sampler output ON THE DEVICE; only rank 0 samples
-        assert not (self.async_scheduling and self.tensor_parallel_size > 1), "async_scheduling needs tensor_parallel_size == 1"
         if self.hf_config is None:
             self.hf_config = load_hf_config(self.model)
         self.max_model_len = min(self.max_model_len, self.hf_config.max_position_embeddings)

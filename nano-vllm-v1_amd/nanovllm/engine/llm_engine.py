@@ -92,7 +92,7 @@ class LLMEngine:
         launched = None
         if not self.scheduler.is_finished():
             seqs = self.scheduler.schedule()
-            tokens = self.model_runner.run_async(seqs)
+            tokens = self.model_runner.call("run_async", seqs)     # every rank launches; rank 0's ids reach the others on the device
             launched = (self.scheduler.advance(seqs, tokens.need), tokens)
         done = []
         if self._inflight is not None:

@@ -159,6 +159,7 @@ class ModelRunner:
         self.event = event
         self.external_group = dist.is_initialized()
         self.shm = None
+        self._msg_seq = 0                       # control channel: messages posted (rank 0) / taken (workers) so far
         self.prev_sampled = None                # run_async: the last sampler output, kept on the device for the next step
         self._token_bufs, self._token_flip = [None, None], 0    # pinned landing buffers of two steps in flight
 
@@ -277,20 +278,38 @@ class ModelRunner:
             if method_name == "exit":
                 break
 
+    # Control channel: one message slot + one event per worker, as in the reference (engine/model_runner.py:195-288),
+    # plus an acknowledgement: the last 64 bytes of the segment hold, per worker, the number of the last message it has
+    # taken.  Rank 0 posts message k+1 only when every worker has taken message k - the reference gets that for free
+    # because its `run` waits for the GPU (and so for every rank) before the next call; a step launched ahead of its
+    # results (`run_async`) returns at once.
+    ACK_BYTES = 64
+
     def read_shm(self):
         assert self.world_size > 1 and self.rank > 0
         self.event.wait()
         n = int.from_bytes(self.shm.buf[0:4], "little")
         method_name, *args = pickle.loads(self.shm.buf[4:n + 4])
         self.event.clear()
+        self._msg_seq += 1
+        at = SHM_BYTES - self.ACK_BYTES + 4 * self.rank
+        self.shm.buf[at:at + 4] = self._msg_seq.to_bytes(4, "little")        # after the clear: the next set cannot be lost
         return method_name, args
 
     def write_shm(self, method_name, *args):
         assert self.world_size > 1 and self.rank == 0
         data = pickle.dumps([method_name, *args])
         n = len(data)
-        if n + 4 > SHM_BYTES:
-            raise RuntimeError(f"control message of {n} bytes exceeds the {SHM_BYTES}-byte shared segment")
+        if n + 4 > SHM_BYTES - self.ACK_BYTES:
+            raise RuntimeError(f"control message of {n} bytes exceeds the {SHM_BYTES - self.ACK_BYTES}-byte shared segment")
+        deadline = time.perf_counter() + 120.0
+        for r in range(1, self.world_size):                                   # everyone has taken the previous message
+            at = SHM_BYTES - self.ACK_BYTES + 4 * r
+            while int.from_bytes(self.shm.buf[at:at + 4], "little") != self._msg_seq:
+                if time.perf_counter() > deadline:
+                    raise RuntimeError(f"rank {r} has not taken control message {self._msg_seq} for 120 s")
+                time.sleep(0)
+        self._msg_seq += 1
         self.shm.buf[0:4] = n.to_bytes(4, "little")
         self.shm.buf[4:n + 4] = data
         for event in self.event:

@@ -87,11 +87,11 @@ class Sequence:
     def __getstate__(self):
         lo, hi = self.num_cached_tokens, self.num_cached_tokens + self.num_new_tokens
         return (self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.num_new_tokens,
-                self.block_table, self.temperature, lo, self.token_ids[lo:hi])
+                self.block_table, self.temperature, lo, self.token_ids[lo:hi], self.pending_slot)
 
     def __setstate__(self, state):
         (self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.num_new_tokens,
-         self.block_table, self.temperature, lo, window) = state
+         self.block_table, self.temperature, lo, window, self.pending_slot) = state
         self.token_ids = _Window(lo, window, self.num_tokens)
         self.last_token = window[-1] if window else -1
 

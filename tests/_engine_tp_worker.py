@@ -1,7 +1,7 @@
 """Worker of tests/test_y_tp_gpu.py: the front-end with tensor_parallel_size 2 as a user runs it (`LLM(...)`
 spawns rank 1, the shared-memory control channel carries every step, weights come from a safetensors
 checkpoint through the shard loaders).  Both ranks share cuda:0 (one-GPU test box, gloo control plane).
-argv: model_dir out_json port"""
+argv: model_dir out_json port [ahead]      (ahead: async_scheduling=True, the engine one step ahead of its sampled ids)"""
 import json
 import os
 import sys
@@ -14,13 +14,14 @@ sys.path.insert(0, str(ROOT / "nano-vllm-v1_amd"))
 
 def main():
     model_dir, out_json, port = sys.argv[1], sys.argv[2], sys.argv[3]
+    ahead = len(sys.argv) > 4 and sys.argv[4] == "ahead"
     os.environ["NANOVLLM_SHARE_DEVICE"] = "1"
     os.environ["NANOVLLM_PORT"] = port
     import torch
     from nanovllm import LLM, SamplingParams, comm
 
     llm = LLM(model_dir, tensor_parallel_size=2, max_num_batched_tokens=200, max_num_seqs=8, max_model_len=2048,
-              num_kvcache_blocks=24, chunked_prefill=True, enforce_eager=False)
+              num_kvcache_blocks=24, chunked_prefill=True, enforce_eager=False, async_scheduling=ahead)
     if comm.active() is None and comm.fallback_reason == "timeout":
         raise RuntimeError("start-up self-test: exchange timed out")
     assert comm.active() is not None, "xGMI exchange not installed"

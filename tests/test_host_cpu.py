@@ -295,13 +295,26 @@ def test_shm_control_plane_roundtrip():
         r0.rank, r1.rank = 0, 1
         r0.shm = r1.shm = shm
         r0.event, r1.event = [ev], ev
+        r0._msg_seq = r1._msg_seq = 0
         s = Sequence(list(range(300)))
-        s.num_new_tokens, s.block_table = 300, [1, 2]
+        s.num_new_tokens, s.block_table, s.pending_slot = 300, [1, 2], 5
         r0.write_shm("run", [s])
         method, args = r1.read_shm()
         assert method == "run" and not ev.is_set()
         (seqs,) = args
-        assert seqs[0][0:300] == list(range(300)) and seqs[0].block_table == [1, 2]
+        assert seqs[0][0:300] == list(range(300)) and seqs[0].block_table == [1, 2] and seqs[0].pending_slot == 5
+        # the next message waits until the worker has taken the previous one: post it from a thread, take it here
+        posted = threading.Thread(target=lambda: r0.write_shm("run_async", [s]))
+        posted.start()
+        posted.join(5)
+        assert not posted.is_alive() and ev.is_set()         # message 1 was acknowledged, so message 2 went out at once
+        blocked = threading.Thread(target=lambda: r0.write_shm("exit"))
+        blocked.start()
+        blocked.join(0.3)
+        assert blocked.is_alive()                             # message 2 has not been taken yet
+        assert r1.read_shm()[0] == "run_async"
+        blocked.join(5)
+        assert not blocked.is_alive() and r1.read_shm()[0] == "exit"
         with pytest.raises(RuntimeError, match="exceeds"):
             r0.write_shm("run", [Sequence(list(range(10))) for _ in range(40000)])
     finally:

@@ -34,10 +34,12 @@ def test_native_parts_with_rccl_sums_capture_into_a_graph():
 
 
 @pytest.mark.gpu
-def test_engine_spawned_tp2_generate_from_checkpoint(tmp_path):
+@pytest.mark.parametrize("loop", ["synchronous", "ahead"])
+def test_engine_spawned_tp2_generate_from_checkpoint(tmp_path, loop):
     """`LLM(tensor_parallel_size=2)` end to end: spawned rank 1, shared-memory control channel, safetensors
     checkpoint through the shard loaders, chunked prefill + decode graphs; every generated id is checked against
-    the single-rank CPU oracle by teacher forcing."""
+    the single-rank CPU oracle by teacher forcing.  "ahead": async_scheduling=True - both ranks launch step n+1 before
+    rank 0 has read step n's ids, which reach rank 1 on the device."""
     import json
     import shutil
     from safetensors.torch import save_file
@@ -54,7 +56,7 @@ def test_engine_spawned_tp2_generate_from_checkpoint(tmp_path):
     save_file({k: v.clone() for k, v in hf_named(w, shape)}, str(model_dir / "model.safetensors"))
     out = tmp_path / "out.json"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NVH_COMM_TIMEOUT_MS="5000")
-    p = subprocess.run([sys.executable, "-u", os.path.join(HERE, "_engine_tp_worker.py"), str(model_dir), str(out), str(_free_port())],
+    p = subprocess.run([sys.executable, "-u", os.path.join(HERE, "_engine_tp_worker.py"), str(model_dir), str(out), str(_free_port()), loop],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=140)
     if p.returncode == NOT_COSCHEDULED:
         from test_y_comm_gpu import timeout_is_scheduling
