@@ -555,7 +555,7 @@ def main():
         out["native_executor"] = runner.native is not None
         if share_device:
             out["config"]["rehearsal"] = "all ranks share cuda:0; not a scaling measurement"
-    if not args.no_extras:
+    def extras():
         # ---- decode at other batch sizes (same sequences, subsets)
         sweep = {}
         for bb in (1, 8, 32, 128):
@@ -621,6 +621,15 @@ def main():
             ctx_sweep[tag] = dict(tok_s=round(bb * k / d2, 1), ms_per_step=round(d2 / k * 1e3, 4),
                                   hbm_frac=round(sb / (d2 / k) / 1e9 / HBM_PEAK_GBS, 4))
         out["decode_context_sweep"] = ctx_sweep
+
+    if not args.no_extras:
+        # the headline above is complete; a failure in the secondary measurements must not lose it (every rank runs the
+        # same code on the same shapes, so an error is raised on all of them alike)
+        try:
+            extras()
+        except Exception as e:  # noqa: BLE001
+            out["extras_error"] = f"{type(e).__name__}: {e}"
+            note(f"extras failed: {out['extras_error']}")
         if world == 1 and args.model == "qwen3-0.6b":
             out["prefill"]["roofline"]["kernel"] = prefill_kernel_roofline(hf)
         if rank == 0 and world == 1:
