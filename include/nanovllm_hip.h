@@ -260,6 +260,18 @@ int32_t nvh_sample_with_noise(const void* logits, int32_t logits_is_f32, int64_t
 int32_t nvh_argmax(const void* logits, int32_t logits_is_f32, int64_t row_stride, int64_t* out,
                    int64_t rows, int64_t vocab, void* workspace, nvh_stream_t stream);
 
+/* Sampling over vocabulary shards without gathering the logits.  The reference gathers every rank's shard of the
+ * logits on rank 0 (layers/embed_head.py:205-209) and samples there (layers/sampler.py:76-80); here every rank picks the
+ * best candidate of its own shard - same noise per column of the full row (col_offset = first column of the shard, a
+ * multiple of 4), same comparison rule - and leaves (score, index) as 8 bf16 bytes per row in ITS segment of
+ * enc [world][rows][8], zeros in the others.  After the ranks' sum over enc (the all-reduce the activations take),
+ * nvh_sample_pick gives every rank the id nvh_sample would have drawn from the gathered row. */
+int64_t nvh_sample_shard_workspace_bytes(int64_t rows, int64_t shard_vocab);
+int32_t nvh_sample_shard(const void* logits, int32_t logits_is_f32, int64_t row_stride, const float* temperatures, void* enc,
+                         int64_t rows, int64_t shard_vocab, int64_t col_offset, int32_t rank, int32_t world,
+                         uint64_t seed, uint64_t offset, void* workspace, nvh_stream_t stream);
+int32_t nvh_sample_pick(const void* enc, int64_t* out, int64_t rows, int32_t world, nvh_stream_t stream);
+
 /* ---- C1/C2: tensor-parallel exchange over xGMI peer mappings.
  * Replaces the NCCL all-reduce after every row-parallel projection (layers/linear.py:407-409) and after the
  * vocabulary-parallel embedding (layers/embed_head.py:128-129).  One rank per process and device.

@@ -99,7 +99,8 @@ template <bool F32, int MODE>
 __global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restrict__ logits, int64_t row_stride,
                                                            const float* __restrict__ temps, const float* __restrict__ noise,
                                                            int64_t* __restrict__ out, ValIdx* __restrict__ cand, int64_t vocab,
-                                                           int64_t slice_len, uint64_t seed, uint64_t offset, bool vec_ok) {
+                                                           int64_t slice_len, uint64_t seed, uint64_t offset, bool vec_ok,
+                                                           int64_t col_offset) {
     __shared__ ValIdx sm_vi[4];
     const int64_t row = blockIdx.y;
     const int64_t lo = (int64_t)blockIdx.x * slice_len;
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restric
                 for (int e = 0; e < 4; ++e) sc[e] = v[u][e];
             } else if constexpr (MODE == 1) {
                 // score = z - ln(E), E = -ln(u), u uniform in (0,1): hardware log2 (1 ulp) is ample for noise
-                uint32_t c[4] = {(uint32_t)(i >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)};
+                // (col_offset: the row is a vocabulary shard; noise and result are those of the full row's columns)
+                uint32_t c[4] = {(uint32_t)((i + col_offset) >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)};
                 philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
                 constexpr float LN2 = 0.6931471805599453f;
 #pragma unroll
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restric
     ValIdx best{best_v, best_i != 0x7fffffff ? lo + best_i : (first < hi ? first : (int64_t)0x7fffffffffffffffLL)};
     best = block_argmax(best, sm_vi);
     if (threadIdx.x == 0) {
-        if (gridDim.x == 1) out[row] = best.i;
+        if (best.i != (int64_t)0x7fffffffffffffffLL) best.i += col_offset;
+        if (out != nullptr && gridDim.x == 1) out[row] = best.i;
         else cand[row * gridDim.x + blockIdx.x] = best;
     }
 }
@@ -212,9 +215,9 @@ static int32_t launch_sample(const char* name, const void* logits, int32_t is_f3
     dim3 grid((unsigned)slices, (unsigned)rows);
     hipStream_t st = (hipStream_t)stream;
     if (is_f32)
-        sample_slice_kernel<true, MODE><<<grid, 256, 0, st>>>(logits, row_stride, temps, noise, out, (ValIdx*)workspace, vocab, slice_len, seed, offset, vec_ok);
+        sample_slice_kernel<true, MODE><<<grid, 256, 0, st>>>(logits, row_stride, temps, noise, out, (ValIdx*)workspace, vocab, slice_len, seed, offset, vec_ok, 0);
     else
-        sample_slice_kernel<false, MODE><<<grid, 256, 0, st>>>(logits, row_stride, temps, noise, out, (ValIdx*)workspace, vocab, slice_len, seed, offset, vec_ok);
+        sample_slice_kernel<false, MODE><<<grid, 256, 0, st>>>(logits, row_stride, temps, noise, out, (ValIdx*)workspace, vocab, slice_len, seed, offset, vec_ok, 0);
     NVH_CHECK_LAUNCH(name);
     if (slices > 1) {
         sample_final_kernel<<<(unsigned)rows, 64, 0, st>>>((const ValIdx*)workspace, out, slices);
@@ -236,4 +239,83 @@ extern "C" int32_t nvh_sample_with_noise(const void* logits, int32_t logits_is_f
                                          const float* temperatures, const float* noise, int64_t* out, int64_t rows,
                                          int64_t vocab, void* workspace, nvh_stream_t stream) {
     return launch_sample<2>("nvh_sample_with_noise", logits, logits_is_f32, row_stride, temperatures, noise, out, rows, vocab, 0, 0, workspace, stream);
+}
+
+// ---- sampling over vocabulary shards (tensor parallelism) without gathering the logits: every rank picks the best
+// candidate of its shard with the noise of the full row's columns, the candidates (score + index: 7 bytes) travel as bf16
+// bytes through the ranks' sum - each rank fills its own segment of `enc` [world][rows][8], zeros elsewhere - and every
+// rank picks the same winner.  Same result as nvh_sample over the gathered row: the candidates are compared with the same
+// rule (higher score, then lower index), whose outcome does not depend on how the row is cut.
+__global__ __launch_bounds__(64) void sample_shard_final_kernel(const ValIdx* __restrict__ cand, int slices, bf16* __restrict__ enc, int rank,
+                                                                int world, int rows) {
+    const int64_t row = blockIdx.x;
+    ValIdx best{-INFINITY, (int64_t)0x7fffffffffffffffLL};
+    for (int s = threadIdx.x; s < slices; s += 64) best = better(best, cand[row * slices + s]);
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+        ValIdx o;
+        o.v = __shfl_xor(best.v, sft, 64);
+        o.i = __shfl_xor(best.i, sft, 64);
+        best = better(best, o);
+    }
+    const uint32_t vb = __float_as_uint(best.v);
+    const uint32_t ib = (uint32_t)(best.i & 0xffffff);
+    for (int t = threadIdx.x; t < world * 8; t += 64) {
+        const int r = t >> 3, k = t & 7;
+        float byte = 0.f;
+        if (r == rank) byte = (float)(k < 4 ? (vb >> (8 * k)) & 255u : k < 7 ? (ib >> (8 * (k - 4))) & 255u : 0u);
+        enc[((int64_t)r * rows + row) * 8 + k] = f2bf(byte);
+    }
+}
+__global__ __launch_bounds__(256) void sample_pick_kernel(const bf16* __restrict__ enc, int64_t* __restrict__ out, int rows, int world) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    ValIdx best{-INFINITY, (int64_t)0x7fffffffffffffffLL};
+    for (int r = 0; r < world; ++r) {
+        const bf16* e = enc + ((int64_t)r * rows + row) * 8;
+        uint32_t vb = 0, ib = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vb |= (uint32_t)bf2f(e[k]) << (8 * k);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ib |= (uint32_t)bf2f(e[4 + k]) << (8 * k);
+        best = better(best, ValIdx{__uint_as_float(vb), (int64_t)ib});
+    }
+    out[row] = best.i;
+}
+
+extern "C" int64_t nvh_sample_shard_workspace_bytes(int64_t rows, int64_t shard_vocab) {
+    return rows * sample_slices(rows, shard_vocab) * (int64_t)sizeof(ValIdx);
+}
+
+extern "C" int32_t nvh_sample_shard(const void* logits, int32_t logits_is_f32, int64_t row_stride, const float* temperatures, void* enc,
+                                    int64_t rows, int64_t shard_vocab, int64_t col_offset, int32_t rank, int32_t world, uint64_t seed,
+                                    uint64_t offset, void* workspace, nvh_stream_t stream) {
+    NVH_REQUIRE(logits && temperatures && enc && workspace && nvh_aligned16(workspace), NVH_EINVAL, "nvh_sample_shard: null pointer");
+    NVH_REQUIRE(shard_vocab > 0 && rows >= 0 && rows <= 65535 && world >= 1 && world <= 8 && rank >= 0 && rank < world, NVH_EINVAL,
+                "nvh_sample_shard: bad shape");
+    NVH_REQUIRE(col_offset >= 0 && col_offset % 4 == 0 && col_offset + shard_vocab <= (1 << 24), NVH_EINVAL,
+                "nvh_sample_shard: the shard must start on a multiple of 4 columns and the vocabulary fit 24 bits");
+    NVH_REQUIRE(((uintptr_t)logits & (logits_is_f32 ? 3 : 1)) == 0, NVH_EINVAL, "nvh_sample_shard: logits misaligned");
+    if (rows == 0) return NVH_OK;
+    const int slices = sample_slices(rows, shard_vocab);
+    const int64_t slice_len = (nvh_cdiv(shard_vocab, slices) + 3) & ~int64_t(3);
+    const bool vec_ok = row_stride % 4 == 0 && ((uintptr_t)logits & (logits_is_f32 ? 15 : 7)) == 0;
+    dim3 grid((unsigned)slices, (unsigned)rows);
+    hipStream_t st = (hipStream_t)stream;
+    if (logits_is_f32)
+        sample_slice_kernel<true, 1><<<grid, 256, 0, st>>>(logits, row_stride, temperatures, nullptr, nullptr, (ValIdx*)workspace, shard_vocab, slice_len, seed, offset, vec_ok, col_offset);
+    else
+        sample_slice_kernel<false, 1><<<grid, 256, 0, st>>>(logits, row_stride, temperatures, nullptr, nullptr, (ValIdx*)workspace, shard_vocab, slice_len, seed, offset, vec_ok, col_offset);
+    NVH_CHECK_LAUNCH("nvh_sample_shard");
+    sample_shard_final_kernel<<<(unsigned)rows, 64, 0, st>>>((const ValIdx*)workspace, slices, (bf16*)enc, rank, world, (int)rows);
+    NVH_CHECK_LAUNCH("nvh_sample_shard");
+    return NVH_OK;
+}
+
+extern "C" int32_t nvh_sample_pick(const void* enc, int64_t* out, int64_t rows, int32_t world, nvh_stream_t stream) {
+    NVH_REQUIRE(enc && out && rows >= 0 && rows <= 65535 && world >= 1 && world <= 8, NVH_EINVAL, "nvh_sample_pick: bad arguments");
+    if (rows == 0) return NVH_OK;
+    sample_pick_kernel<<<(unsigned)nvh_cdiv(rows, 256), 256, 0, (hipStream_t)stream>>>((const bf16*)enc, out, (int)rows, world);
+    NVH_CHECK_LAUNCH("nvh_sample_pick");
+    return NVH_OK;
 }

@@ -30,6 +30,9 @@ SIGNATURES = {
     "nvh_gather_last_rows": (i32, [vp, vp, vp, vp, i64, i64, vp]),
     "nvh_feed_token_ids": (i32, [vp, vp, vp, vp, i64, vp]),
     "nvh_ids_to_bytes_bf16": (i32, [vp, vp, i64, i64, vp]),
+    "nvh_sample_shard_workspace_bytes": (i64, [i64, i64]),
+    "nvh_sample_shard": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i32, i32, u64, u64, vp, vp]),
+    "nvh_sample_pick": (i32, [vp, vp, i64, i32, vp]),
     "nvh_bytes_bf16_to_ids": (i32, [vp, vp, i64, vp]),
     "nvh_gemm_bf16_nt": (i32, [vp, i64, vp, vp, vp, i64, i64, i64, i64, i32, vp, vp]),
     "nvh_gemm_workspace_bytes": (i64, [i64, i64, i32]),

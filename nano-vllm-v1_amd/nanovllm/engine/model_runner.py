@@ -160,6 +160,7 @@ class ModelRunner:
         self.external_group = dist.is_initialized()
         self.shm = None
         self._msg_seq = 0                       # control channel: messages posted (rank 0) / taken (workers) so far
+        self.shard_sampling = False
         self.prev_sampled = None                # run_async: the last sampler output, kept on the device for the next step
         self._token_bufs, self._token_flip = [None, None], 0    # pinned landing buffers of two steps in flight
 
@@ -213,6 +214,10 @@ class ModelRunner:
             use_native = os.environ.get("NANOVLLM_NATIVE", "1") != "0" and not getattr(hf, "attention_bias", True)
             external_sum = comm.all_reduce if (self.world_size > 1 and self.comm is None) else None
             self.native = NativeQwen3(self.model, comm=self.comm, reduce_fn=external_sum) if use_native else None
+            # tensor-parallel ranks sample over their vocabulary shards instead of gathering the logits on rank 0
+            # (NANOVLLM_SHARD_SAMPLING=0: the reference's gather); needs shards that start on a multiple of 4 columns
+            self.shard_sampling = (self.world_size > 1 and self.native is not None and (hf.vocab_size // self.world_size) % 4 == 0
+                                   and os.environ.get("NANOVLLM_SHARD_SAMPLING", "1") != "0")
             self.warmup_model()
             self.allocate_kv_cache()
             if self.native is not None:
@@ -372,7 +377,7 @@ class ModelRunner:
                                      "context_lens", "need")}
         if fb["block_tables"] is not None:
             arrays["block_tables"] = fb["block_tables"]
-        if self.rank == 0:
+        if self.rank == 0 or self.shard_sampling:
             temps = np.fromiter((s.temperature for s in seqs), dtype=np.float32, count=len(seqs))
             arrays["temperatures"] = temps[fb["need"]] if fb["need"].size else temps
         # Mixed step: the running sequences come first with one token each; the native executor sends that prefix
@@ -498,10 +503,11 @@ class ModelRunner:
         return graph
 
     @torch.inference_mode()
-    def forward_logits(self, seqs):
+    def forward_logits(self, seqs, gather=True):
         """Everything of a step up to the sampler: (logits [B', V] | None, temperatures | None, need)
         with ``need`` a HOST int32 tensor (indices into ``seqs`` of the rows of ``logits``).  logits is
-        None on ranks > 0 and when no sequence finishes its scheduled prompt in this step."""
+        None on ranks > 0 and when no sequence finishes its scheduled prompt in this step.  ``gather=False`` (tensor
+        parallelism with the native executor): every rank keeps the logits of ITS vocabulary shard, [B', V / tp]."""
         fb = flatten_batch(seqs, self.block_size)
         fb["fed"] = self._fed_indices(seqs, fb)
         graph = self._graph_for(fb)
@@ -509,9 +515,9 @@ class ModelRunner:
         has_tables = any(len(s.block_table) for s in seqs)
         skip_logits = fb["need"].size == 0 and has_tables
         if graph is not None:
-            hidden, temps = graph.replay(fb, seqs, self.rank == 0, self.prev_sampled)
+            hidden, temps = graph.replay(fb, seqs, self.rank == 0 or not gather, self.prev_sampled)
             rows = hidden[:len(seqs)]
-            logits = self.native.logits(rows) if self.native is not None else self.model.lm_head.forward_rows(rows)
+            logits = self.native.logits(rows, gather=gather) if self.native is not None else self.model.lm_head.forward_rows(rows)
         else:
             input_ids, positions, temps, _ = self.prepare_model_input(seqs, fb)
             hidden = self.forward_hidden(input_ids, positions, fb)
@@ -520,18 +526,34 @@ class ModelRunner:
             elif self.native is not None:
                 ctx = get_context()
                 n = fb["need"].size or len(seqs)
-                logits = self.native.logits(hidden, ctx.cu_seqlens_q, ctx.seq_need_compute_logits if fb["need"].size else None, n)
+                logits = self.native.logits(hidden, ctx.cu_seqlens_q, ctx.seq_need_compute_logits if fb["need"].size else None, n,
+                                            gather=gather)
             else:
                 logits = self.model.compute_logits(hidden)
         reset_context()
         return logits, temps, need_host
 
+    def sample_over_shards(self, shard_logits, temps):
+        """Token ids (int64 on the device, the same on every rank) from the ranks' vocabulary shards of the logits,
+        without gathering them (the reference gathers [B, V] on rank 0, layers/embed_head.py:205-209): every rank
+        offers the best candidate of its shard - drawn with the noise of the full row's columns - and the candidates
+        take the activations' sum over the ranks.  Same ids as the sampler over the gathered logits."""
+        self.sampler.calls += 1
+        shard = shard_logits.shape[1]
+        enc = ops.sample_shard(shard_logits, temps, self.sampler.seed, self.sampler.calls, self.rank * shard, self.rank, self.world_size)
+        comm.all_reduce(enc.view(-1))
+        return ops.sample_pick(enc)
+
     @torch.inference_mode()
     def run(self, seqs):
         t0 = time.perf_counter()
-        logits, temps, need_host = self.forward_logits(seqs)
+        logits, temps, need_host = self.forward_logits(seqs, gather=not self.shard_sampling)
         token_ids = None
-        if self.rank == 0:
+        if self.shard_sampling:
+            ids = None if logits is None else self.sample_over_shards(logits, temps)
+            if self.rank == 0:                  # (every rank holds the ids; the contract hands them to rank 0's caller)
+                token_ids = [] if ids is None else ids.tolist()
+        elif self.rank == 0:
             token_ids = [] if logits is None else self.sampler(logits, temps).tolist()
         if self.comm is not None and time.perf_counter() - t0 > 2.0:
             self.comm.check()                   # a step this slow may have sat through an exchange timeout: raise, do not go on
@@ -556,16 +578,19 @@ class ModelRunner:
         them with `.result()` when it needs them - normally after it has launched the next step.  Under tensor
         parallelism every rank calls it with the same sequences: rank 0 samples, the ids reach the other ranks on the
         device (comm.broadcast_ids), and every rank can read them back."""
-        logits, temps, need_host = self.forward_logits(seqs)
+        logits, temps, need_host = self.forward_logits(seqs, gather=not self.shard_sampling)
         need = need_host.tolist()
         count = len(need) if (need or any(len(s.block_table) for s in seqs)) else len(seqs)
         if count == 0:
             event = torch.cuda.Event()
             event.record()
             return PendingTokens(None, event, need, 0)
-        sampled = self.sampler(logits, temps) if self.rank == 0 else None
-        if self.world_size > 1:
-            sampled = comm.broadcast_ids(sampled, count, self.device)
+        if self.shard_sampling:
+            sampled = self.sample_over_shards(logits, temps)
+        else:
+            sampled = self.sampler(logits, temps) if self.rank == 0 else None
+            if self.world_size > 1:
+                sampled = comm.broadcast_ids(sampled, count, self.device)
         n = sampled.numel()
         self._token_flip ^= 1
         buf = self._token_bufs[self._token_flip]

@@ -159,10 +159,14 @@ class NativeQwen3:
     def workspace_bytes(self, num_tokens: int, batch: int, decode_splits: int) -> int:
         return max(16, self.lib.nvh_qwen3_workspace_bytes(C.byref(self.desc), num_tokens, batch, max(1, decode_splits)))
 
-    def logits(self, hidden, cu_seqlens_q=None, need=None, num_rows=None):
+    def logits(self, hidden, cu_seqlens_q=None, need=None, num_rows=None, gather=True):
         """lm_head over the last scheduled row of the selected sequences (cu_seqlens_q None: `hidden`
-        rows are used directly)."""
+        rows are used directly).  `gather=False` (tensor-parallel ranks): this rank's vocabulary shard [n, vocab_rows]
+        stays where it is - for sampling over the shards (ops.sample_shard)."""
         n = hidden.shape[0] if cu_seqlens_q is None else num_rows
+        if not gather:
+            rows = hidden if cu_seqlens_q is None else ops.gather_last_rows(hidden, cu_seqlens_q, need, n)
+            return ops.linear(rows, self.model.lm_head.weight)
         if self.reduce_fn is not None:
             # this rank's vocabulary shard, then the gather to rank 0 through torch.distributed (layers/embed_head.py:205-209)
             from . import comm as comm_mod

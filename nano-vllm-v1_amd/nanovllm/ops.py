@@ -417,6 +417,30 @@ def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: 
     return out
 
 
+def sample_shard(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int, col_offset: int, rank: int,
+                 world: int) -> torch.Tensor:
+    """Best candidate of every row of a vocabulary shard [rows, shard_vocab] (columns col_offset.. of the full row), as
+    bf16 bytes in this rank's segment of a [world, rows, 8] tensor (zeros elsewhere): sum it over the ranks, then
+    `sample_pick`."""
+    f = _logits_args(logits)
+    rows, vocab = logits.shape
+    assert temperatures.dtype == torch.float32 and temperatures.numel() == rows
+    enc = torch.empty(world, rows, 8, dtype=BF16, device=logits.device)
+    ws = torch.empty(max(16, _hip.lib().nvh_sample_shard_workspace_bytes(rows, vocab)), dtype=torch.uint8, device=logits.device)
+    _hip.call("nvh_sample_shard", logits.data_ptr(), f, logits.stride(0), temperatures.data_ptr(), enc.data_ptr(), rows, vocab,
+              col_offset, rank, world, seed, offset, ws.data_ptr(), _stream())
+    return enc
+
+
+def sample_pick(enc: torch.Tensor) -> torch.Tensor:
+    """The winner per row among the ranks' candidates (`sample_shard` summed over the ranks): int64 [rows]."""
+    world, rows, _ = enc.shape
+    assert enc.dtype == BF16 and enc.is_contiguous()
+    out = torch.empty(rows, dtype=torch.int64, device=enc.device)
+    _hip.call("nvh_sample_pick", enc.data_ptr(), out.data_ptr(), rows, world, _stream())
+    return out
+
+
 def sample_with_noise(logits: torch.Tensor, temperatures: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
     f = _logits_args(logits)
     assert noise.dtype == torch.float32 and noise.is_contiguous() and noise.shape == logits.shape

@@ -158,13 +158,22 @@ def main():
         assert runner.graphs
     if runner.comm is not None:
         runner.comm.check()
+    calls = runner.sampler.calls
+    tok, need = runner.run(seqs)                     # ids for rank 0's caller only
     if rank == 0:
-        tok, need = runner.run(seqs)                 # sampler on rank 0 only
         assert len(tok) == 3
         print(f"max |logit err| vs oracle over the steps: {worst:.4g}")
     else:
-        tok, need = runner.run(seqs)
         assert tok is None
+    assert runner.shard_sampling == (mode != "modules")
+    if runner.shard_sampling:
+        # the ids came from the ranks' vocabulary shards; the sampler over the gathered logits draws the same ones
+        from nanovllm import ops
+        assert runner.sampler.calls == calls + 1
+        logits, temps, _ = runner.forward_logits(seqs)
+        if rank == 0:
+            want = ops.sample(logits, temps, runner.sampler.seed, calls + 1).tolist()
+            assert tok == want, (tok, want)
     if mode in ("native", "graph", "fallback"):
         check_one_step_ahead(runner, seqs, tables, rank, world)
     runner.exit()

@@ -263,6 +263,37 @@ def test_feed_token_ids_copies_sampled_rows_into_the_next_input(ops):
     assert torch.equal(got.cpu(), want)
 
 
+@pytest.mark.parametrize("world,rows,vocab", [(2, 3, 1024), (4, 7, 151936), (8, 256, 151936), (8, 1, 4096)])
+def test_sampling_over_vocabulary_shards_draws_the_gathered_rows_ids(ops, world, rows, vocab):
+    """Every rank offers the best candidate of its shard (noise of the full row's columns), the candidates are summed
+    as bf16 bytes, every rank picks the winner: the ids of the sampler over the whole rows - also when the best score
+    occurs twice (lowest index wins) and at a temperature that makes the noise irrelevant."""
+    g = torch.Generator().manual_seed(world * 1000 + rows)
+    logits = (torch.randn(rows, vocab, generator=g) * 3).to(torch.bfloat16)
+    logits[0, vocab - 5] = logits[0].max() + 1                    # rows whose maximum sits in the last / first shard
+    if rows > 1:
+        logits[rows - 1, 3] = logits[rows - 1].max() + 1
+    temps = torch.full((rows,), 0.8)
+    temps[0] = 1e-6                                               # near-greedy: the planted maximum must win
+    ld, td = dev(logits), dev(temps)
+    want = ops.sample(ld, td, 11, 5)
+    shard = vocab // world
+    enc = None
+    for r in range(world):
+        e = ops.sample_shard(ld[:, r * shard:(r + 1) * shard], td, 11, 5, r * shard, r, world)
+        assert float(e.float().abs().sum() - e[r].float().abs().sum()) == 0.0        # only its own segment
+        enc = e if enc is None else enc + e
+    got = ops.sample_pick(enc.contiguous())
+    assert torch.equal(got.cpu(), want.cpu())
+    assert int(got[0]) == vocab - 5
+    # an exact tie between two shards: the lower index wins, as in the scan over the whole row
+    tie = torch.zeros(1, vocab, dtype=torch.bfloat16)
+    tie[0, shard - 1] = tie[0, shard + 1] = 50.0
+    t1 = dev(torch.full((1,), 1e-9))
+    enc = sum(ops.sample_shard(dev(tie)[:, r * shard:(r + 1) * shard], t1, 3, 1, r * shard, r, world) for r in range(world))
+    assert int(ops.sample_pick(enc.contiguous())[0]) == int(ops.sample(dev(tie), t1, 3, 1)[0]) == shard - 1
+
+
 GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024), (33, 1024, 3072), (64, 1024, 256),
                (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256),
                (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128),   # 256x128 LM-head tile (one / two row tiles)
