@@ -272,6 +272,18 @@ int32_t nvh_sample_shard(const void* logits, int32_t logits_is_f32, int64_t row_
                          uint64_t seed, uint64_t offset, void* workspace, nvh_stream_t stream);
 int32_t nvh_sample_pick(const void* enc, int64_t* out, int64_t rows, int32_t world, nvh_stream_t stream);
 
+/* LM head and sampler in one GEMM launch: ids = nvh_sample(x W^T, temperatures, seed, offset) without the logits ever
+ * reaching memory (layers/embed_head.py:204 followed by layers/sampler.py:76-80 in the reference).  Each workgroup of the
+ * projection scores its 256 columns with the sampler's own noise and comparison rule and leaves one candidate per row in
+ * `workspace` (nvh_lm_head_sample_workspace_bytes); a second small launch picks among the column tiles.  Same ids as the
+ * two separate calls.  Only for shapes that take the 256 x 256 GEMM tile: nvh_lm_head_sample_fused(M, N, K) says so (the
+ * call returns NVH_ENOSYS otherwise). */
+int32_t nvh_lm_head_sample_fused(int64_t M, int64_t N, int64_t K);
+int64_t nvh_lm_head_sample_workspace_bytes(int64_t M, int64_t N);
+int32_t nvh_lm_head_sample(const void* x, int64_t x_row_stride, const void* w, const float* temperatures, int64_t* out,
+                           int64_t M, int64_t N, int64_t K, uint64_t seed, uint64_t offset, void* workspace,
+                           nvh_stream_t stream);
+
 /* ---- C1/C2: tensor-parallel exchange over xGMI peer mappings.
  * Replaces the NCCL all-reduce after every row-parallel projection (layers/linear.py:407-409) and after the
  * vocabulary-parallel embedding (layers/embed_head.py:128-129).  One rank per process and device.

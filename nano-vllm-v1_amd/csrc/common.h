@@ -124,3 +124,49 @@ __device__ __forceinline__ bf16x8 qknorm_rope_head(bf16x8 x, bf16x8 w, const flo
     const f32x4 s1 = *reinterpret_cast<const f32x4*>(cs_row + 64 + 8 * (c & 7) + 4);
     return qknorm_rope_head_cs(x, w, c0, c1, s0, s1, c, eps);
 }
+
+// ---- sampling pieces shared by the sampler kernels and the LM-head GEMM epilogue ------------------
+struct ValIdx {
+    float v;
+    int64_t i;
+};
+__device__ __forceinline__ ValIdx better(ValIdx a, ValIdx b) {
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+// Philox4x32-10 counter generator.
+__device__ __forceinline__ void philox(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)p1;
+        c[3] = (uint32_t)p0;
+        c[0] = n0;
+        c[2] = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+// Scores of the exponential race for 4 consecutive columns col .. col+3 (col a multiple of 4) of `row`:
+// z / T - ln(E), E ~ Exp(1) from Philox keyed by (seed; col / 4, row, offset).  score = z - ln(E), E = -ln(u), u uniform
+// in (0,1): hardware log2 (1 ulp) is ample for noise.  23 random bits -> u = (k + 1/2) * 2^-23: every step is exact in
+// fp32 and u stays inside [2^-24, 1 - 2^-24], so E is never 0; the clamp is the one the reference applies
+// (layers/sampler.py:80, clamp_min_(1e-10)).
+__device__ __forceinline__ void nvh_race_scores(const float (&z)[4], float inv_t, int64_t col, int64_t row, uint64_t seed, uint64_t offset,
+                                                float (&sc)[4]) {
+    uint32_t c[4] = {(uint32_t)(col >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    constexpr float LN2 = 0.6931471805599453f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float un = (float)(c[e] >> 9) * 0x1p-23f + 0x1p-24f;
+        const float ex = fmaxf(-LN2 * __builtin_amdgcn_logf(un), 1e-10f);       // Exp(1) sample
+        sc[e] = __builtin_fmaf(z[e], inv_t, -LN2 * __builtin_amdgcn_logf(ex));
+    }
+}
+
+// Pick among `slices` candidates per row (sampler.hip): out[row] = index of the best.
+int32_t nvh_launch_sample_final(const void* cand, int64_t* out, int64_t rows, int slices, hipStream_t st);

@@ -57,11 +57,22 @@ struct QkvEpilogue {
     int hq, hkv, raw_rows;
 };
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false>
+// Epilogue of the LM-head projection fused with the sampler (SAMPLE): the logits never leave the workgroup.  Each lane
+// holds 4 consecutive columns of a row = one group of the sampler's noise generator; it scores them exactly as
+// sample_slice_kernel does (logit rounded to bf16 first), the workgroup keeps the best candidate per row of its 256
+// columns and leaves it in cand[row][column tile]; nvh_launch_sample_final then picks among the column tiles.
+struct SampleEpilogue {
+    const float* temps;
+    ValIdx* cand;
+    uint64_t seed, offset;
+    int64_t col_offset;       // first column of this (shard of the) vocabulary in the full row
+};
+
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false, bool SAMPLE = false>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split,
-    QkvEpilogue qe, bool wide_store) {
+    QkvEpilogue qe, bool wide_store, SampleEpilogue se) {
     constexpr int NW = WAVES_N * WAVES_M;                 // waves per workgroup (4; 2 for the skinny decode tiles)
     static_assert(NW == 8 || NW == 4 || NW == 2, "2, 4 or 8 waves");
     constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
@@ -220,6 +231,51 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     }
 
     // epilogue: lane holds n = n_base + fq*4 .. +3 of row m = m_base + fr
+    if constexpr (SAMPLE) {
+        static_assert(NW == 8 && !SWIGLU && !QKV, "sampling epilogue: the eight-wave tile");
+        ValIdx (*sm_cand)[TM][16] = reinterpret_cast<ValIdx (*)[TM][16]>(smem);     // the stages are free: every read of them was waited for before the last barrier
+        ValIdx best[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WM + j * 16 + fr;
+            const float inv_t = 1.0f / se.temps[min(m, M - 1)];
+            best[j] = ValIdx{-INFINITY, (int64_t)0x7fffffffffffffffLL};
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {                       // increasing columns: "strictly greater" keeps the lowest index
+                const int n = n0 + wn * WN + i * 16 + fq * 4;
+                if (n >= N) continue;
+                float z[4], sc[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = bf2f(f2bf(acc[i][j][e]));
+                nvh_race_scores(z, inv_t, n + se.col_offset, m, se.seed, se.offset, sc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (sc[e] > best[j].v) best[j] = ValIdx{sc[e], n + e + se.col_offset};
+            }
+            if (best[j].i == (int64_t)0x7fffffffffffffffLL) best[j].i = n0 + wn * WN + fq * 4 + se.col_offset;    // all -inf: offer the first column
+            // the 4 lanes fq = 0..3 of a row, then the two column halves (waves wn = 0, 1) through LDS
+#pragma unroll
+            for (int sft = 16; sft <= 32; sft <<= 1) {
+                ValIdx o;
+                o.v = __shfl_xor(best[j].v, sft, 64);
+                o.i = __shfl_xor(best[j].i, sft, 64);
+                best[j] = better(best[j], o);
+            }
+        }
+        if (wn == 1 && fq == 0) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) sm_cand[wm][j][fr] = best[j];
+        }
+        __syncthreads();
+        if (wn == 0 && fq == 0) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = m0 + wm * WM + j * 16 + fr;
+                if (m < M) se.cand[(int64_t)m * gridDim.x + blockIdx.x] = better(best[j], sm_cand[wm][j][fr]);
+            }
+        }
+        return;
+    }
     if constexpr (QKV) {
         // The tile (one head of BM tokens) goes through LDS as bf16 - the rounding point of the separate GEMM - and
         // is then walked like the stand-alone q/k epilogue kernel: 16 lanes per row, 8 columns per lane, the same
@@ -376,14 +432,15 @@ struct GemmArgs {
     hipStream_t st;
     bool swiglu;
     const QkvEpilogue* qkv = nullptr;   // set: the QKV epilogue (128x128 tiles only)
+    const SampleEpilogue* sample = nullptr;   // set: the sampling epilogue (256x256 tiles only)
 };
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false>
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false, bool SAMPLE = false>
 void launch_gemm_nt(const GemmArgs& a) {
     constexpr int smem = STAGES * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool configured = false;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV, SAMPLE>;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
@@ -395,7 +452,7 @@ void launch_gemm_nt(const GemmArgs& a) {
     const int k_per_split = (int)nvh_cdiv(ktiles, a.split_k) * BK;
     dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
     kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split,
-                                                       a.qkv ? *a.qkv : QkvEpilogue{}, wide);
+                                                       a.qkv ? *a.qkv : QkvEpilogue{}, wide, a.sample ? *a.sample : SampleEpilogue{});
 }
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
@@ -406,6 +463,12 @@ void launch_gemm(const GemmArgs& a) {
         if (a.qkv) {
             if (nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true, false, true>(a);
             else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, false, true>(a);
+            return;
+        }
+    }
+    if constexpr (BM == 256 && BN == 256) {
+        if (a.sample) {
+            launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, false, false, true>(a);
             return;
         }
     }
@@ -657,6 +720,28 @@ extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, 
     return nvh_qknorm_rope_store((bf16*)qkv + raw_rows * qkv_row_stride, qkv_row_stride, num_q_heads, num_kv_heads, q_norm_weight, k_norm_weight,
                                  eps, positions + raw_rows, cos_sin, max_position, k_cache, v_cache, slot_mapping ? slot_mapping + raw_rows : nullptr,
                                  M - raw_rows, stream);
+}
+
+// ---- LM head + sampler in one GEMM launch (+ the pick among the column tiles)
+extern "C" int32_t nvh_lm_head_sample_fused(int64_t M, int64_t N, int64_t K) {
+    return M > 0 && M <= 65535 && N > 0 && N % 4 == 0 && N + 0 < (1 << 30) && K > 0 && K % BK == 0 && pick_tile(M, N, 1) == T256x256;
+}
+extern "C" int64_t nvh_lm_head_sample_workspace_bytes(int64_t M, int64_t N) { return M * nvh_cdiv(N, 256) * (int64_t)sizeof(ValIdx); }
+
+extern "C" int32_t nvh_lm_head_sample(const void* x, int64_t x_row_stride, const void* w, const float* temperatures, int64_t* out,
+                                      int64_t M, int64_t N, int64_t K, uint64_t seed, uint64_t offset, void* workspace,
+                                      nvh_stream_t stream) {
+    NVH_REQUIRE(x && w && temperatures && out && workspace && nvh_aligned16(workspace), NVH_EINVAL, "nvh_lm_head_sample: null pointer");
+    NVH_REQUIRE(x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w), NVH_EINVAL, "nvh_lm_head_sample: x/w rows must be 16-byte aligned");
+    NVH_REQUIRE(nvh_lm_head_sample_fused(M, N, K), NVH_ENOSYS,
+                "nvh_lm_head_sample: %ld x %ld x %ld does not take the 256 x 256 tile (ask nvh_lm_head_sample_fused; use nvh_gemm_bf16_nt + nvh_sample)",
+                (long)M, (long)N, (long)K);
+    SampleEpilogue se{temperatures, (ValIdx*)workspace, seed, offset, 0};
+    GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, nullptr, nullptr, x_row_stride, 0, (int)M, (int)N, (int)K, 1, (hipStream_t)stream, false};
+    a.sample = &se;
+    const int32_t rc = dispatch_gemm(a);
+    if (rc != NVH_OK) return rc;
+    return nvh_launch_sample_final(workspace, out, M, (int)nvh_cdiv(N, 256), (hipStream_t)stream);
 }
 
 // dst rows <- src rows of a merged [gate (I rows) | up (I rows)] weight in the interleaved order above.

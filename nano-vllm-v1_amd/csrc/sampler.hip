@@ -10,13 +10,6 @@
 // rounding of each other.
 #include "common.h"
 
-struct ValIdx {
-    float v;
-    int64_t i;
-};
-__device__ __forceinline__ ValIdx better(ValIdx a, ValIdx b) {
-    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
-}
 __device__ __forceinline__ ValIdx block_argmax(ValIdx x, ValIdx* sm) {
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
@@ -75,23 +68,6 @@ __device__ __forceinline__ void load4(const void* row, int64_t i, int64_t vocab,
     }
 }
 
-// Philox4x32-10 counter generator.
-__device__ __forceinline__ void philox(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-        c[1] = (uint32_t)p1;
-        c[3] = (uint32_t)p0;
-        c[0] = n0;
-        c[2] = n2;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-}
-
 // MODE 0: argmax   MODE 1: sample with generated noise   MODE 2: sample with supplied noise
 // Grid (slices, rows): every workgroup scans one slice of one row and leaves its best candidate in
 // `cand` (or in `out` directly when there is one slice); sample_final_kernel picks among slices.
@@ -132,18 +108,7 @@ __global__ __launch_bounds__(256) void sample_slice_kernel(const void* __restric
             } else if constexpr (MODE == 1) {
                 // score = z - ln(E), E = -ln(u), u uniform in (0,1): hardware log2 (1 ulp) is ample for noise
                 // (col_offset: the row is a vocabulary shard; noise and result are those of the full row's columns)
-                uint32_t c[4] = {(uint32_t)((i + col_offset) >> 2), (uint32_t)row, (uint32_t)offset, (uint32_t)(offset >> 32)};
-                philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-                constexpr float LN2 = 0.6931471805599453f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // 23 random bits -> u = (k + 1/2) * 2^-23: every step is exact in fp32 and u stays inside
-                    // [2^-24, 1 - 2^-24], so E = -ln(u) is never 0; the clamp is the one the reference applies
-                    // (layers/sampler.py:80, clamp_min_(1e-10)).
-                    const float un = (float)(c[e] >> 9) * 0x1p-23f + 0x1p-24f;
-                    const float ex = fmaxf(-LN2 * __builtin_amdgcn_logf(un), 1e-10f);       // Exp(1) sample
-                    sc[e] = __builtin_fmaf(v[u][e], inv_t, -LN2 * __builtin_amdgcn_logf(ex));
-                }
+                nvh_race_scores(v[u], inv_t, i + col_offset, row, seed, offset, sc);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -183,6 +148,12 @@ __global__ __launch_bounds__(64) void sample_final_kernel(const ValIdx* __restri
         best = better(best, o);
     }
     if (threadIdx.x == 0) out[row] = best.i;
+}
+
+int32_t nvh_launch_sample_final(const void* cand, int64_t* out, int64_t rows, int slices, hipStream_t st) {
+    sample_final_kernel<<<(unsigned)rows, 64, 0, st>>>((const ValIdx*)cand, out, slices);
+    NVH_CHECK_LAUNCH("sample_final");
+    return NVH_OK;
 }
 
 static int sample_slices(int64_t rows, int64_t vocab) {

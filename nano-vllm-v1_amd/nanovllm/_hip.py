@@ -33,6 +33,9 @@ SIGNATURES = {
     "nvh_sample_shard_workspace_bytes": (i64, [i64, i64]),
     "nvh_sample_shard": (i32, [vp, i32, i64, vp, vp, i64, i64, i64, i32, i32, u64, u64, vp, vp]),
     "nvh_sample_pick": (i32, [vp, vp, i64, i32, vp]),
+    "nvh_lm_head_sample_fused": (i32, [i64, i64, i64]),
+    "nvh_lm_head_sample_workspace_bytes": (i64, [i64, i64]),
+    "nvh_lm_head_sample": (i32, [vp, i64, vp, vp, vp, i64, i64, i64, u64, u64, vp, vp]),
     "nvh_bytes_bf16_to_ids": (i32, [vp, vp, i64, vp]),
     "nvh_gemm_bf16_nt": (i32, [vp, i64, vp, vp, vp, i64, i64, i64, i64, i32, vp, vp]),
     "nvh_gemm_workspace_bytes": (i64, [i64, i64, i32]),

@@ -161,6 +161,8 @@ class ModelRunner:
         self.shm = None
         self._msg_seq = 0                       # control channel: messages posted (rank 0) / taken (workers) so far
         self.shard_sampling = False
+        # one GPU: batches from about 230 rows sample inside the LM head's GEMM (NANOVLLM_FUSED_HEAD_SAMPLER=0: two launches)
+        self.fused_head = os.environ.get("NANOVLLM_FUSED_HEAD_SAMPLER", "1") != "0"
         self.prev_sampled = None                # run_async: the last sampler output, kept on the device for the next step
         self._token_bufs, self._token_flip = [None, None], 0    # pinned landing buffers of two steps in flight
 
@@ -502,36 +504,71 @@ class ModelRunner:
             return None
         return graph
 
+    def _forward_rows(self, seqs, want_temps):
+        """A step up to the final norm: (hidden, cu_seqlens_q | None, rows to keep | None, row count, temperatures, need).
+        cu_seqlens_q None: the rows of `hidden` are the LM head's rows as they are (a graph replay); a row count of 0: no
+        sequence finishes its scheduled prompt in this step and nothing is to be projected."""
+        fb = flatten_batch(seqs, self.block_size)
+        fb["fed"] = self._fed_indices(seqs, fb)
+        graph = self._graph_for(fb)
+        need_host = torch.from_numpy(fb["need"])
+        if graph is not None:
+            hidden, temps = graph.replay(fb, seqs, want_temps, self.prev_sampled)
+            out = (hidden[:len(seqs)], None, None, len(seqs), temps, need_host)
+        else:
+            input_ids, positions, temps, _ = self.prepare_model_input(seqs, fb)
+            hidden = self.forward_hidden(input_ids, positions, fb)
+            ctx = get_context()
+            if fb["need"].size == 0 and any(len(s.block_table) for s in seqs):
+                out = (hidden, None, None, 0, temps, need_host)
+            elif self.native is not None:
+                out = (hidden, ctx.cu_seqlens_q, ctx.seq_need_compute_logits if fb["need"].size else None,
+                       fb["need"].size or len(seqs), temps, need_host)
+            else:                               # operator modules: the rows ParallelLMHead.forward would select
+                keep = ctx.seq_need_compute_logits if fb["need"].size else None
+                rows = ops.gather_last_rows(hidden, ctx.cu_seqlens_q, keep, fb["need"].size or len(seqs))
+                out = (rows, None, None, rows.shape[0], temps, need_host)
+        reset_context()
+        return out
+
     @torch.inference_mode()
     def forward_logits(self, seqs, gather=True):
         """Everything of a step up to the sampler: (logits [B', V] | None, temperatures | None, need)
         with ``need`` a HOST int32 tensor (indices into ``seqs`` of the rows of ``logits``).  logits is
         None on ranks > 0 and when no sequence finishes its scheduled prompt in this step.  ``gather=False`` (tensor
         parallelism with the native executor): every rank keeps the logits of ITS vocabulary shard, [B', V / tp]."""
-        fb = flatten_batch(seqs, self.block_size)
-        fb["fed"] = self._fed_indices(seqs, fb)
-        graph = self._graph_for(fb)
-        need_host = torch.from_numpy(fb["need"])
-        has_tables = any(len(s.block_table) for s in seqs)
-        skip_logits = fb["need"].size == 0 and has_tables
-        if graph is not None:
-            hidden, temps = graph.replay(fb, seqs, self.rank == 0 or not gather, self.prev_sampled)
-            rows = hidden[:len(seqs)]
-            logits = self.native.logits(rows, gather=gather) if self.native is not None else self.model.lm_head.forward_rows(rows)
+        hidden, cu, keep, n, temps, need_host = self._forward_rows(seqs, self.rank == 0 or not gather)
+        if n == 0:
+            logits = None
+        elif self.native is not None:
+            logits = self.native.logits(hidden, cu, keep, n, gather=gather)
         else:
-            input_ids, positions, temps, _ = self.prepare_model_input(seqs, fb)
-            hidden = self.forward_hidden(input_ids, positions, fb)
-            if skip_logits:
-                logits = None
-            elif self.native is not None:
-                ctx = get_context()
-                n = fb["need"].size or len(seqs)
-                logits = self.native.logits(hidden, ctx.cu_seqlens_q, ctx.seq_need_compute_logits if fb["need"].size else None, n,
-                                            gather=gather)
-            else:
-                logits = self.model.compute_logits(hidden)
-        reset_context()
+            logits = self.model.lm_head.forward_rows(hidden)
         return logits, temps, need_host
+
+    @torch.inference_mode()
+    def forward_sampled(self, seqs):
+        """A whole step: (sampled ids - int64 on the device - | None, need).  None when nothing was to be sampled and,
+        without sampling over the vocabulary shards, on ranks > 0.  Three routes to the same ids: the LM head with
+        the sampler in its epilogue (one GPU, batches that take its 256 x 256 tile: the logits are never written),
+        sampling over the ranks' shards, or the sampler over the (gathered) logits."""
+        if self.fused_head and self.native is not None and self.world_size == 1:
+            hidden, cu, keep, n, temps, need_host = self._forward_rows(seqs, True)
+            if n == 0:
+                return None, need_host
+            w = self.model.lm_head.weight
+            if ops.lm_head_sample_fused(n, w.shape[0], w.shape[1]):
+                rows = hidden if cu is None else ops.gather_last_rows(hidden, cu, keep, n)
+                self.sampler.calls += 1
+                return ops.lm_head_sample(rows, w, temps, self.sampler.seed, self.sampler.calls), need_host
+            logits = self.native.logits(hidden, cu, keep, n)
+        else:
+            logits, temps, need_host = self.forward_logits(seqs, gather=not self.shard_sampling)
+        if logits is None:
+            return None, need_host
+        if self.shard_sampling:
+            return self.sample_over_shards(logits, temps), need_host
+        return self.sampler(logits, temps), need_host
 
     def sample_over_shards(self, shard_logits, temps):
         """Token ids (int64 on the device, the same on every rank) from the ranks' vocabulary shards of the logits,
@@ -547,14 +584,10 @@ class ModelRunner:
     @torch.inference_mode()
     def run(self, seqs):
         t0 = time.perf_counter()
-        logits, temps, need_host = self.forward_logits(seqs, gather=not self.shard_sampling)
+        ids, need_host = self.forward_sampled(seqs)
         token_ids = None
-        if self.shard_sampling:
-            ids = None if logits is None else self.sample_over_shards(logits, temps)
-            if self.rank == 0:                  # (every rank holds the ids; the contract hands them to rank 0's caller)
-                token_ids = [] if ids is None else ids.tolist()
-        elif self.rank == 0:
-            token_ids = [] if logits is None else self.sampler(logits, temps).tolist()
+        if self.rank == 0:                      # (with shard sampling every rank holds the ids; the contract hands them to rank 0's caller)
+            token_ids = [] if ids is None else ids.tolist()
         if self.comm is not None and time.perf_counter() - t0 > 2.0:
             self.comm.check()                   # a step this slow may have sat through an exchange timeout: raise, do not go on
         return token_ids, need_host
@@ -578,19 +611,15 @@ class ModelRunner:
         them with `.result()` when it needs them - normally after it has launched the next step.  Under tensor
         parallelism every rank calls it with the same sequences: rank 0 samples, the ids reach the other ranks on the
         device (comm.broadcast_ids), and every rank can read them back."""
-        logits, temps, need_host = self.forward_logits(seqs, gather=not self.shard_sampling)
+        sampled, need_host = self.forward_sampled(seqs)
         need = need_host.tolist()
         count = len(need) if (need or any(len(s.block_table) for s in seqs)) else len(seqs)
         if count == 0:
             event = torch.cuda.Event()
             event.record()
             return PendingTokens(None, event, need, 0)
-        if self.shard_sampling:
-            sampled = self.sample_over_shards(logits, temps)
-        else:
-            sampled = self.sampler(logits, temps) if self.rank == 0 else None
-            if self.world_size > 1:
-                sampled = comm.broadcast_ids(sampled, count, self.device)
+        if self.world_size > 1 and not self.shard_sampling:
+            sampled = comm.broadcast_ids(sampled, count, self.device)
         n = sampled.numel()
         self._token_flip ^= 1
         buf = self._token_bufs[self._token_flip]

@@ -417,6 +417,25 @@ def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: 
     return out
 
 
+def lm_head_sample_fused(m: int, n: int, k: int) -> bool:
+    """Whether `lm_head_sample` covers an [m, k] x [n, k]^T projection (it takes the 256 x 256 GEMM tile)."""
+    return bool(_hip.lib().nvh_lm_head_sample_fused(m, n, k))
+
+
+def lm_head_sample(x: torch.Tensor, weight: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int) -> torch.Tensor:
+    """sample(x @ W^T, temperatures, seed, offset) in one GEMM launch + a pick: the logits are never written."""
+    _gpu_bf16(x, weight)
+    m, k = x.shape
+    n = weight.shape[0]
+    assert x.stride(1) == 1 and weight.is_contiguous() and weight.shape[1] == k
+    assert temperatures.dtype == torch.float32 and temperatures.numel() == m
+    out = torch.empty(m, dtype=torch.int64, device=x.device)
+    ws = torch.empty(_hip.lib().nvh_lm_head_sample_workspace_bytes(m, n), dtype=torch.uint8, device=x.device)
+    _hip.call("nvh_lm_head_sample", x.data_ptr(), x.stride(0), weight.data_ptr(), temperatures.data_ptr(), out.data_ptr(), m, n, k,
+              seed, offset, ws.data_ptr(), _stream())
+    return out
+
+
 def sample_shard(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int, col_offset: int, rank: int,
                  world: int) -> torch.Tensor:
     """Best candidate of every row of a vocabulary shard [rows, shard_vocab] (columns col_offset.. of the full row), as

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 MODEL = str(Path(__file__).resolve().parent.parent / "nano-vllm-v1_amd" / "model_configs" / "qwen3-0.6b")
 
 
-def make(enforce_eager, budget=1024, pages=40):
+def make(enforce_eager, budget=1024, pages=40, max_seqs=16):
     os.environ["NANOVLLM_NATIVE"] = "1"
     from nanovllm.config import Config
     from nanovllm.engine.model_runner import ModelRunner
-    cfg = Config(MODEL, max_num_batched_tokens=budget, max_num_seqs=16, max_model_len=4096, enforce_eager=enforce_eager,
+    cfg = Config(MODEL, max_num_batched_tokens=budget, max_num_seqs=max_seqs, max_model_len=4096, enforce_eager=enforce_eager,
                  num_kvcache_blocks=pages, chunked_prefill=True)
     return ModelRunner(cfg, 0, [])
 
@@ -228,3 +228,46 @@ def test_kv_pool_sized_from_free_memory():
         assert need.tolist() == [0] and bool(torch.isfinite(logits.float()).all())
     finally:
         runner.exit()
+
+
+def test_sampler_inside_the_lm_head_draws_the_ids_of_the_two_launches():
+    """256 sequences: the LM head takes its 256 x 256 tile and samples in its epilogue (the logits are never written).
+    Same ids as the projection followed by the sampler at temperature 0.8 - a prefill step that selects the last rows
+    of 256 prompts, then decode steps through the captured graph - and 255 sequences take the two launches."""
+    r = make(False, budget=1024, pages=260, max_seqs=256)
+    try:
+        ps = prompts([3] * 256, 9)
+        w = r.model.lm_head.weight
+        from nanovllm import ops
+        assert ops.lm_head_sample_fused(256, w.shape[0], w.shape[1]) and not ops.lm_head_sample_fused(200, w.shape[0], w.shape[1])
+
+        def three_steps(fused, count):
+            r.fused_head, r.sampler.calls = fused, 0
+            seqs = [seq(p, 0, len(p), [i]) for i, p in enumerate(ps[:count])]
+            for s in seqs:
+                s.temperature = 0.8
+            drawn = []
+            for _ in range(3):
+                ids, need = r.run(seqs)
+                assert len(ids) == count
+                drawn.append(ids)
+                for s, t in zip(seqs, ids):
+                    s.num_cached_tokens += s.num_new_tokens
+                    s.append_token(t)
+                    s.num_new_tokens = 1
+            return drawn
+
+        calls = []
+        real = ops.lm_head_sample
+        ops.lm_head_sample = lambda *a: (calls.append(a[0].shape[0]), real(*a))[1]
+        try:
+            a = three_steps(True, 256)
+            assert calls == [256, 256, 256]
+            assert three_steps(False, 256) == a and len(calls) == 3
+            assert len(set(a[2])) > 100                         # sampled, not a constant
+            three_steps(True, 200)
+            assert len(calls) == 3                              # too few rows for the tile: projection, then sampler
+        finally:
+            ops.lm_head_sample = real
+    finally:
+        r.exit()

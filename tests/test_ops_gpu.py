@@ -294,6 +294,29 @@ def test_sampling_over_vocabulary_shards_draws_the_gathered_rows_ids(ops, world,
     assert int(ops.sample_pick(enc.contiguous())[0]) == int(ops.sample(dev(tie), t1, 3, 1)[0]) == shard - 1
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 151936, 256), (230, 151936, 128), (460, 151936, 64), (1024, 16384, 192), (700, 30000, 64)])
+def test_lm_head_with_sampler_in_its_epilogue_draws_the_separate_calls_ids(ops, m, n, k):
+    """The projection whose workgroups score their own 256 columns (logits never written) against the projection
+    followed by the sampler (reference: layers/embed_head.py:204 then layers/sampler.py:76-80): the same ids, bit for
+    bit - ragged rows, a half-empty last column tile, near-greedy rows, and a row whose best logit occurs twice."""
+    assert ops.lm_head_sample_fused(m, n, k)
+    assert not ops.lm_head_sample_fused(64, n, k) and not ops.lm_head_sample_fused(m, 1024, k)
+    x, w = rnd(m, k, seed=m + 3), rnd(n, k, seed=n + k, scale=0.2)
+    w[n - 1] = w[7]                                               # columns 7 and n-1 give the same logit in every row
+    x[1] = 40 * w[7] / w[7].norm()                                # ... and row 1 makes it the largest by far
+    temps = torch.rand(m, generator=torch.Generator().manual_seed(k)) * 1.2 + 0.3
+    temps[0] = temps[1] = 1e-6                                    # near-greedy
+    xd, wd, td = dev(x), dev(w), dev(temps)
+    logits = ops.linear(xd, wd)
+    for seed, offset in [(0, 0), (1234567, 99)]:
+        want = ops.sample(logits, td, seed, offset)
+        got = ops.lm_head_sample(xd, wd, td, seed, offset)
+        assert torch.equal(got.cpu(), want.cpu())
+    assert int(got[1]) == 7 and int(got[0]) == int(logits[0].float().argmax())
+    with pytest.raises(RuntimeError):
+        ops.lm_head_sample(xd[:64], wd, td[:64], 0, 0)            # does not take the 256 x 256 tile: refused, not computed otherwise
+
+
 GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024), (33, 1024, 3072), (64, 1024, 256),
                (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256),
                (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128),   # 256x128 LM-head tile (one / two row tiles)
