@@ -499,7 +499,9 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     // big products (prefill of the 14B / 32B shapes, square GEMMs from 4096 up, the LM head from 256 rows): 256 x 256
     // tiles in eight-wave workgroups once they fill the chip and few of their rows are padding (4096^3: 985 -> 1196
     // TFLOP/s; 1024 x 34816 x 5120: 705 -> 877; LM head at 256 / 512 rows: 132 -> 118 / 244 -> 215 us; 128 tiles: 983 -> 710)
-    if (!no256 && split_k == 1 && wgs(256, 256) >= 240 && nvh_cdiv(M, 256) * 256 * 8 <= M * 9) return T256x256;
+    // ... also for K-slabs when tiles x slabs make ONE nearly full round (Qwen3-14B o / down at 1024 rows: 80 tiles x 3
+    // slabs, 73 -> 55 us and 188 -> 157 us against 128-row tiles with the best slab count)
+    if (!no256 && wgs(256, 256) >= 240 && (split_k == 1 || wgs(256, 256) <= 256) && nvh_cdiv(M, 256) * 256 * 8 <= M * 9) return T256x256;
     // very wide outputs with few rows: all rows in one tile, so every weight row is fetched once; three stages, one
     // workgroup per CU
     if (!no256 && M >= 256 && M <= 512 && wgs(256, 128) >= 768) return T256x128;
@@ -599,6 +601,30 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
     static const int s128 = getenv("NVH_GEMM_S128") ? atoi(getenv("NVH_GEMM_S128")) : 0;   // tuning switches
     static const int s64 = getenv("NVH_GEMM_S64") ? atoi(getenv("NVH_GEMM_S64")) : 0;
     const Tile tile = pick_tile(a.M, a.N, a.split_k);
+    if (tile == T256x256 && a.split_k == 1 && !a.sample && !a.qkv) {
+        // One 256 x 256 workgroup fits a CU, so the grid runs in rounds of 256 tiles and a last round with few tiles
+        // costs a whole round (Qwen3-14B gate/up at 1024 rows: 544 tiles, 403 us; 512 tiles 300 us).  Columns that make
+        // whole rounds go first; a remainder of at most half a round follows as a launch of its own on the tile that
+        // fits IT (34 us for the 32 left-over tiles above).
+        static const bool no_cut = getenv("NVH_GEMM_NO_ROUND_CUT") != nullptr;       // A/B switch for measurements
+        const int64_t tm = nvh_cdiv(a.M, 256), tn = nvh_cdiv(a.N, 256);
+        int64_t g = tm, r = 256;
+        while (r) { const int64_t t = g % r; g = r; r = t; }                         // gcd(tm, 256)
+        const int64_t cols_per_round = 256 / g;                                      // column tiles that complete whole rounds
+        const int64_t main_tn = tn / cols_per_round * cols_per_round;
+        const int64_t rest = (tn - main_tn) * tm;
+        if (!no_cut && main_tn > 0 && rest > 0 && rest <= 128) {
+            GemmArgs head = a, tail = a;
+            const int64_t n_head = main_tn * 256;
+            head.N = (int)n_head;
+            tail.N = a.N - (int)n_head;
+            tail.w = a.w + n_head * a.K;
+            tail.y = a.y + (a.swiglu ? n_head / 2 : n_head);
+            if (a.bias) tail.bias = a.bias + n_head;
+            const int32_t rc = dispatch_gemm(head);
+            return rc != NVH_OK ? rc : dispatch_gemm(tail);
+        }
+    }
     if (tile == T128x128 && s128 == 3) { launch_gemm<128, 128, 2, 2, 3>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
     if (tile == T128x128 && s128 == 4) { launch_gemm<128, 128, 2, 2, 4>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
     if (tile == T64x64 && s64 == 6) { launch_gemm<64, 64, 2, 2, 6>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }

@@ -321,7 +321,8 @@ GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024
                (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256),
                (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128),   # 256x128 LM-head tile (one / two row tiles)
                (5, 26624, 192), (40, 4096, 1024), (64, 7168, 512),         # 16x64 two-wave tile; 64x64 at 33..64 rows
-               (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64)]   # 256x256 eight-wave tile (full, ragged, one k-tile)
+               (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64),   # 256x256 eight-wave tile (full, ragged, one k-tile)
+               (1024, 17408, 128), (512, 35000, 64)]                       # ... whole rounds + a remainder launch on smaller tiles
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -344,9 +345,21 @@ def test_gemm_bias_strided_input_and_splitk(ops):
         assert_gemm(ops.splitk_reduce(slabs, dev(b)), ref)
 
 
+@pytest.mark.parametrize("m,n,k,s", [(1024, 5120, 384, 3), (1000, 5000, 512, 3), (512, 5120, 384, 6), (2048, 2560, 256, 3)])
+def test_gemm_k_slabs_on_the_256_tile(ops, m, n, k, s):
+    """Tiles x slabs of one nearly full round take the eight-wave 256 x 256 tile (the Qwen3-14B o / down projections at
+    1024 rows): slabs summed by the reduce kernel and by add + RMSNorm against the oracle's linear."""
+    x, w = rnd(m, k, seed=m + 1), rnd(n, k, seed=n + 2, scale=0.05)
+    ref = R.linear(x, w)
+    slabs = ops.linear_splitk(dev(x), dev(w), s)
+    assert slabs.shape == (s, m, n)
+    assert_gemm(ops.splitk_reduce(slabs), ref)
+    assert_gemm(ops.linear(dev(x), dev(w)), ref)
+
+
 @pytest.mark.parametrize("m,inter,k", [(1, 3072, 1024), (20, 512, 256), (256, 3072, 1024), (1024, 3072, 1024), (70, 96, 192),
                                        (3, 13312, 128), (16, 17408, 64), (48, 3072, 256),    # 16x64 tile (832 / 1088 narrow tiles)
-                                       (1024, 8192, 256)])                                   # 256x256 eight-wave tile
+                                       (1024, 8192, 256), (1024, 8704, 128)])                # 256x256 eight-wave tile; with a remainder launch
 def test_gemm_swiglu_epilogue_bit_identical_to_separate_kernels(ops, m, inter, k):
     x, w = rnd(m, k, seed=m + 1), rnd(2 * inter, k, seed=k + 2, scale=0.05)
     xd, wd = dev(x), dev(w)
