@@ -61,6 +61,18 @@ __device__ __forceinline__ int k_off(int row, int ch) {          // K tile
     return 256 * row + 16 * (ch ^ (row & 15));
 }
 
+// Scheduling request for the region it stands in: four times {one MFMA, then N VALU instructions}.
+template <int N>
+__device__ __forceinline__ void interleave_mfma_valu() {
+    if constexpr (N > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, N, 0);
+        }
+    }
+}
+
 template <int G, int RB, int KS, int STAGES, bool PAGED>
 __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS == 2 ? 2 : 1)) void attn_varlen_kernel(
     const bf16* __restrict__ q, int64_t q_stride, const bf16* __restrict__ kp, const bf16* __restrict__ vp,
@@ -208,16 +220,28 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
             int kb[8];
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) kb[ks] = kb0 ^ ((32 * ks) ^ soff);
+            // The fragments of step ks + 1 are requested before the MFMAs of step ks are issued (two register sets), so an
+            // LDS round trip hides behind two MFMAs instead of standing between every pair; the two 32-key halves are
+            // independent accumulation chains that share the Q fragment.
+            // (inline asm with counted waits: the compiler drains the LDS queue - lgkmcnt(0) - at every other step)
+            bf16x8 kf[2][2];
+            auto request = [&](int ks, bf16x8 (&dst)[2]) {
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:8192" : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(kb[ks]) : "memory");
+            };
+            request(0, kf[0]);
 #pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2) {
-                if (t2) __builtin_amdgcn_sched_barrier(0);      // 8 K fragments (32 registers) in flight, not 16
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks) {
-                    if (ks == 2 || ks == 4 || ks == 6) __builtin_amdgcn_sched_barrier(0);
-                    const bf16x8 kfrag = *reinterpret_cast<LDS_AS const bf16x8*>(lds + kb[ks] + 8192 * t2);
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    st[t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qf[ks], ks == 0 ? zero : st[t2], 0, 0, 0);   // (zero: an inline operand)
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks + 1 < 8) {
+                    request(ks + 1, kf[(ks + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kf[ks & 1][0]), "+v"(kf[ks & 1][1])::"memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[ks & 1][0]), "+v"(kf[ks & 1][1])::"memory");
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                st[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][0], qf[ks], ks == 0 ? zero : st[0], 0, 0, 0);   // (zero: an inline operand)
+                st[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks & 1][1], qf[ks], ks == 0 ? zero : st[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         // ---- online softmax of st (query on the lane), in three slices so that they can sit between the MFMA groups of
@@ -228,7 +252,7 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
         float alpha = 1.0f, neg_m = 0.f;
         bool resc = false;
         f32x2 psum2 = {0.f, 0.f};
-        auto sm_max = [&](int kt, bool masked) {
+        auto sm_mask = [&](int kt, bool masked) {
             if (masked) {
                 const int vis = qrow + shift - kt * 64 - 4 * hh;   // last visible key, relative to the lane's first
 #pragma unroll
@@ -237,6 +261,8 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
                     for (int r = 0; r < 16; ++r)
                         st[t2][r] = (t2 * 32 + (r & 3) + 8 * (r >> 2)) > vis ? -INFINITY : st[t2][r];
             }
+        };
+        auto sm_max = [&]() {
             float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -282,10 +308,10 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
         // are issued from inline asm: as compiler-visible loads they would each be preceded by a vmcnt(0) (LDS reads are
         // ordered after every LDS-DMA in flight), which drains the prefetched tiles.  lgkmcnt(0) is the only wait (LDS
         // returns in order; over-waiting is safe).
-        auto pv_block = [&](int slot, int dt, const bf16x8 (&pc)[2][2]) {
+        struct VFrags { bf16x4 lo[4], hi[4]; };
+        auto pv_request = [&](int slot, int dt, VFrags& f) {
             const int soff = slot * STAGE;
             const int v0 = vb0 ^ ((16 * ((4 * dt) ^ 0)) ^ soff), v1 = vb0 ^ ((16 * ((4 * dt) ^ 2)) ^ soff);
-            bf16x4 vl[4], vh[4];
             asm volatile(
                 "ds_read_b64_tr_b16 %0, %8 offset:16384\n\t"
                 "ds_read_b64_tr_b16 %1, %9 offset:18432\n\t"
@@ -294,18 +320,27 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
                 "ds_read_b64_tr_b16 %4, %8 offset:24576\n\t"
                 "ds_read_b64_tr_b16 %5, %9 offset:26624\n\t"
                 "ds_read_b64_tr_b16 %6, %8 offset:28672\n\t"
-                "ds_read_b64_tr_b16 %7, %9 offset:30720\n\t"
-                "s_waitcnt lgkmcnt(0)"
-                : "=&v"(vl[0]), "=&v"(vh[0]), "=&v"(vl[1]), "=&v"(vh[1]), "=&v"(vl[2]), "=&v"(vh[2]), "=&v"(vl[3]), "=&v"(vh[3])
+                "ds_read_b64_tr_b16 %7, %9 offset:30720"
+                : "=&v"(f.lo[0]), "=&v"(f.hi[0]), "=&v"(f.lo[1]), "=&v"(f.hi[1]), "=&v"(f.lo[2]), "=&v"(f.hi[2]), "=&v"(f.lo[3]), "=&v"(f.hi[3])
                 : "v"(v0), "v"(v1)
                 : "memory");
+        };
+        // OUTSTANDING = LDS reads requested after these fragments that may stay in flight (LDS returns in order)
+        auto pv_mfma = [&](int dt, VFrags& f, const bf16x8 (&pc)[2][2], auto outstanding) {
+            constexpr int OUTSTANDING = decltype(outstanding)::value;
+            if constexpr (OUTSTANDING == 8)
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), "+v"(f.hi[3])::"memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]), "+v"(f.lo[3]), "+v"(f.hi[3])::"memory");
             __builtin_amdgcn_sched_barrier(0);                   // no MFMA above the wait
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                        // u = 2*t2 + sft: keys 32*t2 + 16*sft ..
-                const bf16x8 vfrag = __builtin_shufflevector(vl[u], vh[u], 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 vfrag = __builtin_shufflevector(f.lo[u], f.hi[u], 0, 1, 2, 3, 4, 5, 6, 7);
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pc[u >> 1][u & 1], o[dt], 0, 0, 0);
             }
         };
+        using Ahead = std::integral_constant<int, 8>;
+        using Last = std::integral_constant<int, 0>;
 
         // this wave's tile of step s: its key tile, whether it exists / is visible, whether it crosses the causal diagonal
         auto tile_of = [&](int s) { return kt_beg + s * KS + ks_id; };
@@ -352,7 +387,8 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
         // (page_ring[j] is now the page of step j; at the top of iteration s it is shifted to hold steps s .. s + STAGES)
         if (tile_valid(0)) {
             s_phase(slot_of(0));
-            sm_max(tile_of(0), tile_masked(0));
+            sm_mask(tile_of(0), tile_masked(0));
+            sm_max();
             sm_exp(0, pb);
             sm_exp(1, pb);
             sm_finish();
@@ -373,22 +409,36 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
             const int vslot = slot_of(s);
             if (tile_valid(s + 1)) {
                 // scores of the next tile, then its softmax in the shadow of this tile's P.V MFMAs
+                // (the first V fragments are requested before the score MFMAs and land behind them; every later block is
+                // requested before the MFMAs of the block ahead of it)
+                VFrags vf[2];
+                pv_request(vslot, 0, vf[0]);
                 s_phase(slot_of(s + 1));
                 bf16x8 pn[2][2];
+                sm_mask(tile_of(s + 1), tile_masked(s + 1));
+                // each block of 4 MFMAs (one accumulator: every MFMA waits for the one before it) shares its scheduling
+                // region with a slice of the softmax, and the scheduler is told to put VALU instructions between the MFMAs:
+                // a wave issues in order, so a softmax slice placed after the block would only start once the last
+                // MFMA of the chain has been ISSUED, i.e. after three full MFMA latencies with nothing else to do
                 __builtin_amdgcn_sched_barrier(0);
-                pv_block(vslot, 0, pb);
+                pv_request(vslot, 1, vf[1]);
+                pv_mfma(0, vf[0], pb, Ahead{});
+                sm_max();
+                interleave_mfma_valu<4>();
                 __builtin_amdgcn_sched_barrier(0);
-                sm_max(tile_of(s + 1), tile_masked(s + 1));
-                __builtin_amdgcn_sched_barrier(0);
-                pv_block(vslot, 1, pb);
-                __builtin_amdgcn_sched_barrier(0);
+                pv_request(vslot, 2, vf[0]);
+                pv_mfma(1, vf[1], pb, Ahead{});
                 sm_exp(0, pn);
+                asm volatile("" : "+v"(pn[0][0]), "+v"(pn[0][1]), "+v"(psum2));     // computed HERE, not sunk below the branches
+                interleave_mfma_valu<10>();
                 __builtin_amdgcn_sched_barrier(0);
-                pv_block(vslot, 2, pb);
-                __builtin_amdgcn_sched_barrier(0);
+                pv_request(vslot, 3, vf[1]);
+                pv_mfma(2, vf[0], pb, Ahead{});
                 sm_exp(1, pn);
+                asm volatile("" : "+v"(pn[1][0]), "+v"(pn[1][1]), "+v"(psum2));
+                interleave_mfma_valu<10>();
                 __builtin_amdgcn_sched_barrier(0);
-                pv_block(vslot, 3, pb);
+                pv_mfma(3, vf[1], pb, Last{});
                 __builtin_amdgcn_sched_barrier(0);
                 sm_finish();
                 rescale_o();                                     // after the whole product against the old max
@@ -397,8 +447,18 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) pb[t2][k2] = pn[t2][k2];
             } else {
+                VFrags vf[2];
+                pv_request(vslot, 0, vf[0]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) pv_block(vslot, dt, pb);
+                for (int dt = 0; dt < 4; ++dt) {
+                    if (dt < 3) {
+                        pv_request(vslot, dt + 1, vf[(dt + 1) & 1]);
+                        pv_mfma(dt, vf[dt & 1], pb, Ahead{});
+                    } else {
+                        pv_mfma(dt, vf[dt & 1], pb, Last{});
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -577,7 +637,15 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
         // measured and not kept for 2 query heads per kv head: 32-row blocks (twice the K/V staging per MFMA), 128-row
         // blocks (half the workgroups; 99.9 us against 98 at 8192 keys in 4 ranges) and a ring of 4 steps instead of 2 (no
         // change: the loop is bound by instruction issue, not by the DMA latency)
-        case 2: if (ks == 2) LAUNCH_VL(2, 2, 2, 2); else LAUNCH_VL(2, 2, 1, 2); break;
+        case 2: {
+            // a grid that leaves half the CUs without a workgroup (one 1024-token chunk: 16 blocks x 8 kv heads): 32-row
+            // blocks put a four-wave workgroup on every CU instead of an eight-wave one on every other
+            static const int rb1 = getenv("NVH_ATTN_RB1") ? atoi(getenv("NVH_ATTN_RB1")) : 128;     // A/B switch: 0 = never
+            if (ks == 2 && wgs <= rb1) LAUNCH_VL(2, 1, 2, 2);
+            else if (ks == 2) LAUNCH_VL(2, 2, 2, 2);
+            else LAUNCH_VL(2, 2, 1, 2);
+            break;
+        }
         case 4: if (ks == 2) LAUNCH_VL(4, 1, 2, 2); else LAUNCH_VL(4, 1, 1, 2); break;
         case 5: LAUNCH_VL(5, 1, 1, 2); break;
         case 8: LAUNCH_VL(8, 1, 1, 2); break;
