@@ -501,7 +501,11 @@ Tile pick_tile(int64_t M, int64_t N, int split_k) {
     // TFLOP/s; 1024 x 34816 x 5120: 705 -> 877; LM head at 256 / 512 rows: 132 -> 118 / 244 -> 215 us; 128 tiles: 983 -> 710)
     // ... also for K-slabs when tiles x slabs make ONE nearly full round (Qwen3-14B o / down at 1024 rows: 80 tiles x 3
     // slabs, 73 -> 55 us and 188 -> 157 us against 128-row tiles with the best slab count)
-    if (!no256 && wgs(256, 256) >= 240 && (split_k == 1 || wgs(256, 256) <= 256) && nvh_cdiv(M, 256) * 256 * 8 <= M * 9) return T256x256;
+    // Rows: up to one row tile, at most 1/8 of it padding; beyond that the 256-row tiles never compute more than 4/3 of the
+    // rows 128-row tiles would, and a 256 x 256 tile costs about three 128 x 128 ones (LM head, 151936 x 1024, at
+    // 300 / 520 / 850 rows: 193 / 283 / 402 us against 209 / 338 / 484 us)
+    const bool rows_ok = (M <= 256 || split_k > 1) ? nvh_cdiv(M, 256) * 256 * 8 <= M * 9 : true;   // (K-slabs: measured on full row tiles only)
+    if (!no256 && wgs(256, 256) >= 240 && (split_k == 1 || wgs(256, 256) <= 256) && rows_ok) return T256x256;
     // very wide outputs with few rows: all rows in one tile, so every weight row is fetched once; three stages, one
     // workgroup per CU
     if (!no256 && M >= 256 && M <= 512 && wgs(256, 128) >= 768) return T256x128;

@@ -294,7 +294,8 @@ def test_sampling_over_vocabulary_shards_draws_the_gathered_rows_ids(ops, world,
     assert int(ops.sample_pick(enc.contiguous())[0]) == int(ops.sample(dev(tie), t1, 3, 1)[0]) == shard - 1
 
 
-@pytest.mark.parametrize("m,n,k", [(256, 151936, 256), (230, 151936, 128), (460, 151936, 64), (1024, 16384, 192), (700, 30000, 64)])
+@pytest.mark.parametrize("m,n,k", [(256, 151936, 256), (230, 151936, 128), (460, 151936, 64), (1024, 16384, 192), (700, 30000, 64),
+                                   (300, 151936, 64), (850, 151936, 64)])           # row tiles with 41 % / 17 % padding
 def test_lm_head_with_sampler_in_its_epilogue_draws_the_separate_calls_ids(ops, m, n, k):
     """The projection whose workgroups score their own 256 columns (logits never written) against the projection
     followed by the sampler (reference: layers/embed_head.py:204 then layers/sampler.py:76-80): the same ids, bit for
@@ -319,7 +320,7 @@ def test_lm_head_with_sampler_in_its_epilogue_draws_the_separate_calls_ids(ops, 
 
 GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024), (33, 1024, 3072), (64, 1024, 256),
                (100, 4096, 1024), (128, 1024, 1024), (300, 6144, 1024), (1024, 1024, 3072), (5, 151936, 256),
-               (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128),   # 256x128 LM-head tile (one / two row tiles)
+               (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128), (400, 50176, 128),   # LM head: 256x256 tile, padded rows; 256x128 tile (two row tiles)
                (5, 26624, 192), (40, 4096, 1024), (64, 7168, 512),         # 16x64 two-wave tile; 64x64 at 33..64 rows
                (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64),   # 256x256 eight-wave tile (full, ragged, one k-tile)
                (1024, 17408, 128), (512, 35000, 64)]                       # ... whole rounds + a remainder launch on smaller tiles
