@@ -346,6 +346,14 @@ def test_gemm_bias_strided_input_and_splitk(ops):
         assert_gemm(ops.splitk_reduce(slabs, dev(b)), ref)
 
 
+def test_gemm_bias_across_the_round_cut(ops):
+    """A 256 x 256 grid cut into a whole-round launch and a remainder launch: the bias and the output columns of the
+    remainder start where the first launch ended."""
+    m, n, k = 1024, 17408, 64
+    x, w, b = rnd(m, k, seed=31), rnd(n, k, seed=32, scale=0.05), rnd(n, seed=33)
+    assert_gemm(ops.linear(dev(x), dev(w), dev(b)), R.linear(x, w, b))
+
+
 @pytest.mark.parametrize("m,n,k,s", [(1024, 5120, 384, 3), (1000, 5000, 512, 3), (512, 5120, 384, 6), (2048, 2560, 256, 3)])
 def test_gemm_k_slabs_on_the_256_tile(ops, m, n, k, s):
     """Tiles x slabs of one nearly full round take the eight-wave 256 x 256 tile (the Qwen3-14B o / down projections at
