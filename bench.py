@@ -510,15 +510,18 @@ def main():
     ptimes = driver.prefill(seqs, 1024, ahead)
     note("prefill done")
     steady = [x for x in ptimes[len(ptimes) // 4:]] or ptimes
-    chunk_s = sum(x[0] for x in steady) / len(steady)
-    chunk_tokens = sum(x[1] for x in steady) / len(steady)
-    chunk_flops = sum(algorithmic_flops_per_chunk(hf, x[1], x[2], world) for x in steady) / len(steady)
-    prefill = dict(tok_s=round(chunk_tokens / chunk_s, 1), ms_per_chunk=round(chunk_s * 1e3, 3),
-                   chunk_tokens=int(chunk_tokens), chunks_timed=len(steady),
-                   roofline=dict(bound="mfma", achieved=round(chunk_flops / chunk_s / 1e12, 2), peak=MFMA_PEAK_TFLOPS,
-                                 unit="TFLOP/s", frac=round(chunk_flops / chunk_s / 1e12 / MFMA_PEAK_TFLOPS, 4)),
-                   note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included"
-                        + (" (engine one step ahead: a chunk's time is the interval between consecutive completions)" if ahead else ""))
+    if steady:
+        chunk_s = sum(x[0] for x in steady) / len(steady)
+        chunk_tokens = sum(x[1] for x in steady) / len(steady)
+        chunk_flops = sum(algorithmic_flops_per_chunk(hf, x[1], x[2], world) for x in steady) / len(steady)
+        prefill = dict(tok_s=round(chunk_tokens / chunk_s, 1), ms_per_chunk=round(chunk_s * 1e3, 3),
+                       chunk_tokens=int(chunk_tokens), chunks_timed=len(steady),
+                       roofline=dict(bound="mfma", achieved=round(chunk_flops / chunk_s / 1e12, 2), peak=MFMA_PEAK_TFLOPS,
+                                     unit="TFLOP/s", frac=round(chunk_flops / chunk_s / 1e12 / MFMA_PEAK_TFLOPS, 4)),
+                       note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included"
+                            + (" (engine one step ahead: a chunk's time is the interval between consecutive completions)" if ahead else ""))
+    else:
+        prefill = dict(note="fewer than two chunks in the prefill of this batch: not timed")
 
     # ---- the timed region: K decode steps of B sequences
     dt = time_decode(driver, seqs, args.steps, args.warmup, distributed, ahead=ahead)

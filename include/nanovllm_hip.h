@@ -157,6 +157,21 @@ int32_t nvh_gemm_swiglu_bf16_nt(const void* x, int64_t x_row_stride, const void*
                                 int64_t y_row_stride, int64_t M, int64_t N, int64_t K, nvh_stream_t stream);
 int32_t nvh_interleave_gate_up(const void* w, void* w_interleaved, int64_t inter, int64_t K, nvh_stream_t stream);
 
+/* Residual add + RMSNorm + the projection that consumes it in ONE launch, for decode-sized batches: what
+ * Qwen3DecoderLayer.forward does between two projections (models/qwen3.py:335-349: input_layernorm /
+ * post_attention_layernorm with residual, layers/layernorm.py:95-141, then qkv_proj / gate_up_proj,
+ * layers/linear.py:198).  s = f32(prev) + f32(residual_in) with prev [M, K] bf16, or bf16(sum of `num_slabs` fp32
+ * split-K slabs [num_slabs, M, K]) when `slabs` is non-null; residual_out <- bf16(s) (must NOT alias residual_in);
+ * y[M, N] = rmsnorm(s) w[N, K]^T, or with swiglu != 0 y[M, N/2] = silu(gate) * up over a weight interleaved by
+ * nvh_interleave_gate_up.  Same bits as nvh_add_rmsnorm followed by nvh_gemm_bf16_nt / nvh_gemm_swiglu_bf16_nt.
+ * 1..32 rows, K a multiple of 64 up to 1024 (NVH_ENOSYS otherwise).  Every workgroup derives the rows again, so it pays only
+ * while that is a few KB: nvh_add_rmsnorm_gemm_fused says whether a caller should take it. */
+int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* slabs, int64_t num_slabs, const void* residual_in,
+                                     void* residual_out, const void* norm_weight, float eps, const void* w, void* y,
+                                     int64_t y_row_stride, int64_t M, int64_t N, int64_t K, int32_t swiglu,
+                                     nvh_stream_t stream);
+int32_t nvh_add_rmsnorm_gemm_fused(int64_t M, int64_t N, int64_t K, int64_t num_slabs, int32_t swiglu);
+
 /* ---- K2: paged / packed var-len causal GQA attention (prefill, chunked prefill, mixed).
  * layers/attention.py:236-248 (flash_attn_varlen_func).  q [T,Hq,D] packed by
  * cu_seqlens_q[B+1].  block_tables == NULL: k,v are the packed new tokens [Tk,Hkv,D]

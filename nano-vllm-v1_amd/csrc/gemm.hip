@@ -422,6 +422,346 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     }
 }
 
+// ------------------------------------------------------------------ residual add + RMSNorm in the GEMM's prologue
+// Decode batches: the add + RMSNorm launch in front of a projection moves a few KB and costs a whole dependent
+// launch.  Here every workgroup derives the normalised rows itself - same arithmetic, lane for lane, as
+// rmsnorm_kernel<64, 2, true, PARTIALS> (slab p into partial sum p mod 4, (s0 + s1) + (s2 + s3), one bf16 rounding,
+// residual add, sum of squares per lane in chunk order, wave_sum) - and keeps them in LDS as the MFMA "B" operand
+// of every k-tile: [K / 64][BM rows][128 B], chunks XOR-swizzled like the ring's.  The weight ring is the generic
+// kernel's (the DMA of the first tiles is issued before the prologue) and so are the MFMA order and the epilogues,
+// hence the same bits as nvh_add_rmsnorm followed by nvh_gemm_bf16_nt / nvh_gemm_swiglu_bf16_nt.  Workgroup 0 writes
+// the new residual to res_out, which must not alias res_in (other workgroups may still be reading it).
+struct NormPrologue {
+    const bf16* prev;        // bf16 output of the previous projection [M, K]; ignored when slabs != null
+    const float* slabs;      // its split-K slabs [num_slabs][M][K] (fp32)
+    const bf16* res_in;
+    bf16* res_out;
+    const bf16* norm_w;
+    float eps;
+    int num_slabs;
+};
+
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool SWIGLU>
+__global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
+    NormPrologue np, const bf16* __restrict__ w, bf16* __restrict__ y, int64_t y_stride, int M, int N, int K) {
+    // Nine waves: eight normalise rows (row r goes to wave r mod 8), the first WAVES_N x WAVES_M of them then multiply,
+    // and the ninth does nothing but request the workgroup's weight slice (every k-tile has a stage of its own:
+    // K <= 64 STAGES) and wait for it tile by tile.  A wave's loads retire in order, so a wave that requested both would
+    // see its rows only after the whole slice had landed.
+    constexpr int NW = WAVES_N * WAVES_M;
+    constexpr int PWAVES = 8;                             // waves that normalise rows; the first NW of them go on to multiply
+    static_assert(NW <= PWAVES, "compute waves are prologue waves");
+    constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;
+    constexpr int TN = WN / 16, TM = WM / 16;
+    static_assert(TN >= 1 && TM >= 1, "wave tile");
+    constexpr int A_BYTES = BN * 128;
+    constexpr int A_GROUPS = BN / 8;                      // 8-row x 128-B pieces = one DMA each
+    static_assert(A_GROUPS * (STAGES - 1) < 64, "the loader's tiles in flight must fit the 6-bit vmcnt");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* panel = smem + STAGES * A_BYTES;                // [K / 64][BM][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    const int n0 = blockIdx.x * BN;
+    const int ntiles = K / BK;                            // <= STAGES (checked on the host)
+
+    if (wave == PWAVES) {
+        const int dma_r = lane >> 3, dma_pos = lane & 7;
+        const bf16* src_row[A_GROUPS];
+#pragma unroll
+        for (int p = 0; p < A_GROUPS; ++p) {
+            const int r = p * 8 + dma_r;
+            src_row[p] = w + (int64_t)min(n0 + r, N - 1) * K + (dma_pos ^ ((r >> 1) & 7)) * 8;
+        }
+        for (int t = 0; t < ntiles; ++t) {
+#pragma unroll
+            for (int p = 0; p < A_GROUPS; ++p)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[p] + t * BK), (LDS_AS void*)(smem + t * A_BYTES + p * 1024), 16, 0, 2);
+        }
+        for (int t = 0; t < ntiles; ++t) {
+            wait_tiles_in_flight<A_GROUPS, STAGES - 1>(ntiles - 1 - t);      // tile t has landed
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        return;
+    }
+
+    // ---- prologue: rows wave, wave + PWAVES, .. of the batch (the waves past NW only help here)
+    const int nchunk = K >> 3;
+    bf16x8 wv[2];                                         // requested ahead of the rows: no second trip to memory after the reduction
+#pragma unroll
+    for (int i = 0; i < 2; ++i) wv[i] = *reinterpret_cast<const bf16x8*>(np.norm_w + min(lane + i * 64, nchunk - 1) * 8);
+    // residual add, sum of squares, scale and weight of one row whose projection output (bf16 values) is in xv
+    auto finish_row = [&](int row, float (&xv)[2][8], const bf16x8 (&rs)[2]) {
+        bf16x8 nr[2];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (lane + i * 64 < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xv[i][j] = xv[i][j] + bf2f(rs[i][j]);
+                    nr[i][j] = f2bf(xv[i][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += xv[i][j] * xv[i][j];
+            }
+        }
+        ss = wave_sum(ss);
+        const float inv = 1.0f / sqrtf(ss / (float)K + np.eps);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(xv[i][j] * inv)) * bf2f(wv[i][j]));
+                *reinterpret_cast<bf16x8*>(panel + (c >> 3) * (BM * 128) + row * 128 + (((c & 7) ^ ((row >> 1) & 7)) << 4)) = o;
+                if (blockIdx.x == 0) *reinterpret_cast<bf16x8*>(np.res_out + (int64_t)row * K + c * 8) = nr[i];
+            }
+        }
+    };
+    if (np.slabs != nullptr) {
+        for (int row = wave; row < M; row += PWAVES) {
+            float xv[2][8];
+            bf16x8 rs[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = lane + i * 64;
+                if (c < nchunk) {
+                    rs[i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)row * K + c * 8);
+                    float acc[4][8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
+                    }
+                    const float* src0 = np.slabs + (int64_t)row * K + c * 8;
+                    const int64_t slab = (int64_t)M * K;
+                    int p = 0;
+                    for (; p + 4 <= np.num_slabs; p += 4) {
+                        f32x4 a[4], b[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            a[u] = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab);
+                            b[u] = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab + 4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { acc[u][j] += a[u][j]; acc[u][4 + j] += b[u][j]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        if (p + u < np.num_slabs) {
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab);
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { acc[u][j] += a[j]; acc[u][4 + j] += b[j]; }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[i][j] = bf2f(f2bf((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])));
+                }
+            }
+            finish_row(row, xv, rs);
+        }
+    } else {
+        // up to 32 rows over PWAVES = 8 waves: a wave's rows (at most 4) are all requested before the first is reduced
+        static_assert(PWAVES * 4 >= 32, "rows per wave");
+        bf16x8 pv[4][2], rs[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave + q * PWAVES;
+            if (row < M) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = min(lane + i * 64, nchunk - 1);
+                    pv[q][i] = *reinterpret_cast<const bf16x8*>(np.prev + (int64_t)row * K + c * 8);
+                    rs[q][i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)row * K + c * 8);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave + q * PWAVES;
+            if (row < M) {
+                float xv[2][8];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[i][j] = bf2f(pv[q][i][j]);
+                finish_row(row, xv, rs[q]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's rows are in the panel before it ends or meets the first barrier
+    if (wave >= NW) return;                                // helper waves (a wave that has ended counts as arrived at every barrier)
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // the loader wave passes it once tile t has landed
+        asm volatile("" ::: "memory");
+        const char* a_base = smem + t * A_BYTES;
+        const char* b_base = panel + t * (BM * 128);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TN], bfr[TM];
+            const int kc = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * WN + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(a_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = min(wm * WM + j * 16 + fr, M - 1);       // rows past the batch shadow its last row
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if constexpr (SWIGLU) {
+#pragma unroll
+        for (int i = 0; i + 1 < TN; i += 2) {
+            const int n = n0 + wn * WN + i * 16;
+            if (n >= N) continue;
+            const int col = (n >> 5) * 16 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = wm * WM + j * 16 + fr;
+                if (m >= M) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gv = bf2f(f2bf(acc[i][j][e]));
+                    const float uv = bf2f(f2bf(acc[i + 1][j][e]));
+                    const float sl = gv / (1.0f + expf(-gv));
+                    o[e] = f2bf(bf2f(f2bf(sl)) * uv);
+                }
+                *reinterpret_cast<bf16x4*>(y + (int64_t)m * y_stride + col) = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * WN + i * 16 + fq * 4;
+            if (n >= N) continue;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = wm * WM + j * 16 + fr;
+                if (m >= M) continue;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e]);
+                *reinterpret_cast<bf16x4*>(y + (int64_t)m * y_stride + n) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ narrow outputs over a long K, decode batches
+// The O and down projections of a decode step: a few rows, 1024 output columns, K of 2048..3072.  Tiles of 32 columns
+// give 32 workgroups, so the generic kernel cuts K into fp32 slabs (more workgroups) and leaves their sum to the
+// consumer - which then cannot be a kernel that re-derives its input per workgroup.  Here a workgroup owns 16 output
+// columns over the WHOLE K and its KW waves split K between them: wave w requests its own k-tiles of the 16 weight
+// rows (LDS-DMA, 128-B rows, the ring's swizzle) and the matching x fragments (global -> registers) up front, waits once,
+// multiplies, and the partial tiles meet in LDS: ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)), one bf16 rounding.
+// No barrier until that sum: a wave reads only what it requested itself.
+template <int TM, int KW>
+__global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
+    const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
+    bf16* __restrict__ y, int64_t y_stride, int M, int N, int K) {
+    static_assert(KW == 4 || KW == 8, "four or eight waves over K");
+    constexpr int MAXT = 8;                               // k-tiles per wave (K <= 64 * KW * MAXT)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16;
+    const int ntiles = K / BK;
+    const int per = (ntiles + KW - 1) / KW;               // <= MAXT (checked on the host)
+    const int t0 = wave * per, t1 = min(ntiles, t0 + per);
+    char* mine = smem + wave * (per * 2048);              // this wave's k-tiles: [tile][16 rows][128 B]
+
+    const int dma_r = lane >> 3, dma_pos = lane & 7;
+    const bf16* src[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = p * 8 + dma_r;
+        src[p] = w + (int64_t)min(n0 + r, N - 1) * K + (dma_pos ^ ((r >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        if (t0 + i < t1) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src[p] + (t0 + i) * BK), (LDS_AS void*)(mine + i * 2048 + p * 1024), 16, 0, 2);
+        }
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    bf16x8 xf[TM][MAXT][2];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const bf16* xrow = x + (int64_t)min(j * 16 + fr, M - 1) * x_stride + fq * 8;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+            if (t0 + i < t1) {
+                xf[j][i][0] = *reinterpret_cast<const bf16x8*>(xrow + (t0 + i) * BK);
+                xf[j][i][1] = *reinterpret_cast<const bf16x8*>(xrow + (t0 + i) * BK + 32);
+            }
+        }
+    }
+    f32x4 acc[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        if (t0 + i < t1) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int kc = ks * 4 + fq;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(mine + i * 2048 + fr * 128 + ((kc ^ ((fr >> 1) & 7)) << 4));
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[j][i][ks], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // the partial tiles meet in LDS (past the k-tiles: other waves may still be reading theirs)
+    f32x4* part = reinterpret_cast<f32x4*>(smem + KW * per * 2048);          // [KW][TM][64]
+#pragma unroll
+    for (int j = 0; j < TM; ++j) part[(wave * TM + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    if (wave >= TM) return;
+    const int j = wave;                                   // wave j finishes row tile j
+    f32x4 s[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k) s[k] = part[(k * TM + j) * 64 + lane];
+    f32x4 tot;
+    if constexpr (KW == 8) tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    else tot = (s[0] + s[1]) + (s[2] + s[3]);
+    const int n = n0 + fq * 4, m = j * 16 + fr;
+    if (n < N && m < M) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf(tot[e] + (bias ? bf2f(bias[n + e]) : 0.f));
+        *reinterpret_cast<bf16x4*>(y + (int64_t)m * y_stride + n) = o;
+    }
+}
+
 namespace {
 struct GemmArgs {
     const bf16 *x, *w, *bias;
@@ -601,7 +941,31 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
     return dispatch_gemm(a);
 }
 
+// Decode batches, narrow output, long K (the O / down projections): gemm_kwaves_bf16_nt_kernel.
+static bool takes_kwaves(const GemmArgs& a) {
+    static const bool off = getenv("NVH_NO_KWAVES") != nullptr;                   // A/B switch for measurements
+    return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= 32 && a.K >= 1536 && a.K <= 4096 &&
+           nvh_cdiv(a.N, 32) < 96;
+}
+template <int TM, int KW>
+static void launch_kwaves(const GemmArgs& a) {
+    auto kern = gemm_kwaves_bf16_nt_kernel<TM, KW>;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KW * 8 * 2048 + KW * TM * 1024);
+        configured = true;
+    }
+    const int per = (int)nvh_cdiv(a.K / BK, KW);
+    kern<<<(unsigned)nvh_cdiv(a.N, 16), 64 * KW, KW * per * 2048 + KW * TM * 1024, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M, a.N, a.K);
+}
+
 static int32_t dispatch_gemm(const GemmArgs& a) {
+    if (takes_kwaves(a)) {
+        if (a.K / BK >= 32) { if (a.M <= 16) launch_kwaves<1, 8>(a); else launch_kwaves<2, 8>(a); }
+        else { if (a.M <= 16) launch_kwaves<1, 4>(a); else launch_kwaves<2, 4>(a); }
+        NVH_CHECK_LAUNCH("gemm_kwaves_bf16_nt");
+        return NVH_OK;
+    }
     static const int s128 = getenv("NVH_GEMM_S128") ? atoi(getenv("NVH_GEMM_S128")) : 0;   // tuning switches
     static const int s64 = getenv("NVH_GEMM_S64") ? atoi(getenv("NVH_GEMM_S64")) : 0;
     const Tile tile = pick_tile(a.M, a.N, a.split_k);
@@ -750,6 +1114,55 @@ extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, 
     return nvh_qknorm_rope_store((bf16*)qkv + raw_rows * qkv_row_stride, qkv_row_stride, num_q_heads, num_kv_heads, q_norm_weight, k_norm_weight,
                                  eps, positions + raw_rows, cos_sin, max_position, k_cache, v_cache, slot_mapping ? slot_mapping + raw_rows : nullptr,
                                  M - raw_rows, stream);
+}
+
+// ---- residual add + RMSNorm + projection in one launch (decode batches)
+namespace {
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool SWIGLU>
+void launch_gemm_addnorm(const NormPrologue& np, const bf16* w, bf16* y, int64_t ys, int M, int N, int K, hipStream_t st) {
+    auto kern = gemm_addnorm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, SWIGLU>;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * BN * 128 + BM * 1024 * 2);
+        configured = true;
+    }
+    const int smem = STAGES * BN * 128 + BM * K * 2;
+    kern<<<(unsigned)nvh_cdiv(N, BN), 64 * 9, smem, st>>>(np, w, y, ys, M, N, K);
+}
+}  // namespace
+
+extern "C" int32_t nvh_add_rmsnorm_gemm_fused(int64_t M, int64_t N, int64_t K, int64_t num_slabs, int32_t swiglu) {
+    const bool off = getenv("NVH_NO_NORM_GEMM") != nullptr;                        // A/B switch for measurements and tests (read per call)
+    // KB a workgroup reads to derive the rows again (every workgroup of the grid does): beyond this the norm launch is cheaper
+    static const int64_t budget_kb = getenv("NVH_NORM_GEMM_KB") ? atoll(getenv("NVH_NORM_GEMM_KB")) : 128;
+    if (off || M < 1 || M > 32 || K < BK || K > 1024 || K % BK != 0 || N < 1 || N >= (1 << 30) || num_slabs < 0 || num_slabs > 64) return 0;
+    if (swiglu ? N % 32 != 0 : N % 4 != 0) return 0;
+    const int64_t kb = M * (num_slabs > 0 ? num_slabs * 4 * K : 2 * K) / 1024;
+    return kb <= budget_kb;
+}
+
+extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* slabs, int64_t num_slabs, const void* residual_in,
+                                                void* residual_out, const void* norm_weight, float eps, const void* w, void* y,
+                                                int64_t y_row_stride, int64_t M, int64_t N, int64_t K, int32_t swiglu,
+                                                nvh_stream_t stream) {
+    NVH_REQUIRE(residual_in && residual_out && norm_weight && w && y && (prev || slabs), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: null pointer");
+    NVH_REQUIRE(residual_in != residual_out, NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: residual_out must not alias residual_in");
+    NVH_REQUIRE(nvh_aligned16(residual_in) && nvh_aligned16(residual_out) && nvh_aligned16(norm_weight) && nvh_aligned16(w) &&
+                    (slabs ? nvh_aligned16(slabs) : nvh_aligned16(prev)) && ((uintptr_t)y & 7) == 0 && y_row_stride % 4 == 0,
+                NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: alignment");
+    NVH_REQUIRE(!slabs || (num_slabs >= 1 && num_slabs <= 64), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: num_slabs %ld out of range", (long)num_slabs);
+    NVH_REQUIRE(M >= 1 && M <= 32 && K >= BK && K <= 1024 && K % BK == 0 && N >= 1 && N < (1 << 30) && (swiglu ? N % 32 == 0 : N % 4 == 0),
+                NVH_ENOSYS, "nvh_add_rmsnorm_gemm_bf16_nt: %ld x %ld x %ld unsupported (1..32 rows, K a multiple of 64 up to 1024; ask nvh_add_rmsnorm_gemm_fused)",
+                (long)M, (long)N, (long)K);
+    NormPrologue np{(const bf16*)prev, slabs, (const bf16*)residual_in, (bf16*)residual_out, (const bf16*)norm_weight, eps,
+                    slabs ? (int)num_slabs : 0};
+    hipStream_t st = (hipStream_t)stream;
+    // 16 stages = every k-tile of a 1024-wide row
+    if (swiglu) launch_gemm_addnorm<32, 32, 1, 2, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    else if (M <= 16) launch_gemm_addnorm<16, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    else launch_gemm_addnorm<32, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    NVH_CHECK_LAUNCH("gemm_addnorm_bf16_nt");
+    return NVH_OK;
 }
 
 // ---- LM head + sampler in one GEMM launch (+ the pick among the column tiles)

@@ -9,7 +9,7 @@
 namespace {
 constexpr int32_t kMaxVarlenSplits = 8;
 struct Workspace {
-    bf16 *residual, *x, *y, *qkv, *attn, *gate_up, *act;
+    bf16 *residual, *residual2, *x, *y, *qkv, *attn, *gate_up, *act;
     float* slabs;
     void* decode_ws;
     void* varlen_ws;
@@ -35,6 +35,7 @@ Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_
     int64_t off = 0;
     auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
     w.residual = (bf16*)take(t * h * 2);
+    w.residual2 = (bf16*)take((t <= 32 ? t : 0) * h * 2);   // decode batches: the residual alternates between two buffers (see forward_impl)
     w.x = (bf16*)take(t * h * 2);
     w.y = (bf16*)take(t * h * 2);
     w.qkv = (bf16*)take(t * (qsz + 2 * kvsz) * 2);
@@ -117,7 +118,11 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     const float scale = 1.0f / sqrtf((float)d);
     // partial sums of different ranks meet in bf16: no split-K slab hand-off under tensor parallelism
     const bool sharded = md->comm || external;
-    const int32_t so = sharded ? 1 : split_for(t, h, qsz), sd = sharded ? 1 : split_for(t, h, md->inter);
+    // decode batches whose add + norm happens in the next projection's prologue: no slabs either (every workgroup of
+    // that projection would sum them again); the O / down projections then split K between the waves of a workgroup
+    const bool no_full_k = getenv("NVH_DECODE_SLABS") != nullptr;                 // A/B switch for measurements and tests (read per call)
+    const bool full_k = !no_full_k && t <= 16 && !md->comm && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, 0, 0);
+    const int32_t so = sharded || full_k ? 1 : split_for(t, h, qsz), sd = sharded || full_k ? 1 : split_for(t, h, md->inter);
     auto runs = [&](int part) { return part >= first_part && part <= last_part; };
     const int32_t sq = split_for_qkv(t, qkv_n, h);
 
@@ -140,15 +145,33 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     const bool pending_slabs = sd > 1;
     const int32_t pending_count = sd > 1 ? sd : 0;
     bf16* const pending_y = sd > 1 ? nullptr : w.y;
+    // Decode batches without the built-in exchange: the add + norm in front of the QKV and the gate/up projection
+    // happens in that projection's own prologue (one launch less each).  Such a launch reads the residual from one
+    // buffer and writes it to the other, so the residual stream alternates between w.residual and w.residual2; which
+    // one holds it follows from the number of fused sites passed (the same for every layer, so a step cut into
+    // parts agrees with itself).
+    const bool fuse_in = !comm && t <= 32 && sq == 1 && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, pending_count, 0);
+    const bool fuse_post = !comm && t <= 32 && nvh_add_rmsnorm_gemm_fused(t, 2 * md->inter, h, so > 1 ? so : 0, 1) &&
+                           nvh_add_rmsnorm_gemm_fused(t, 2 * md->inter, h, so > 1 ? so : 0, 0);
+    auto residual_after = [&](int in_sites, int post_sites) {
+        const int swaps = (fuse_in ? in_sites : 0) + (fuse_post ? post_sites : 0);
+        return (swaps & 1) ? w.residual2 : w.residual;
+    };
     for (int l = 0; l < md->layers; ++l) {
       if (runs(2 * l + 1)) {
         // ---- input norm: layer 0 normalises the embedding; later layers add the MLP output first
+        bf16* const res = residual_after(l > 0 ? l - 1 : 0, l);     // input sites of layers 1..l-1, post sites of layers 0..l-1
+        bool qkv_done = false;
         if (l == 0) {
-            FWD(nvh_rmsnorm(w.residual, h, md->input_norm[l], w.x, h, t, h, md->eps, stream));
+            FWD(nvh_rmsnorm(res, h, md->input_norm[l], w.x, h, t, h, md->eps, stream));
+        } else if (fuse_in) {
+            FWD(nvh_add_rmsnorm_gemm_bf16_nt(pending_y, pending_slabs ? w.slabs : nullptr, pending_count, res, residual_after(l, l),
+                                             md->input_norm[l], md->eps, md->qkv_w[l], w.qkv, qkv_n, t, qkv_n, h, 0, stream));
+            qkv_done = true;
         } else if (comm && fused_exchange) {
-            FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->input_norm[l], w.x, t, h, md->eps, stream));
+            FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, res, md->input_norm[l], w.x, t, h, md->eps, stream));
         } else {
-            FWD(nvh_add_rmsnorm(pending_y, w.residual, md->input_norm[l], w.x, t, h, md->eps,
+            FWD(nvh_add_rmsnorm(pending_y, res, md->input_norm[l], w.x, t, h, md->eps,
                                 pending_slabs ? w.slabs : nullptr, pending_count, stream));
         }
         // ---- attention block
@@ -158,7 +181,9 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
         static const bool fuse_decode = getenv("NVH_NO_FUSED_DECODE") == nullptr;   // A/B switch for measurements
         const bool decode_fused = st->mode == NVH_MODE_DECODE && store && fuse_decode;
         bool qk_done = false;               // the q/k epilogue and the KV store of rows prefix.. already happened
-        if (sq > 1) {
+        if (qkv_done) {
+            // (projected in the launch above)
+        } else if (sq > 1) {
             FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, nullptr, qkv_n, t, qkv_n, h, sq, w.slabs, stream));
             FWD(nvh_splitk_reduce(w.slabs, sq, nullptr, w.qkv, qkv_n, t, qkv_n, stream));
         } else if (!decode_fused && t > prefix && d == 128) {
@@ -202,18 +227,28 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
       }
       if (runs(2 * l + 2)) {
         // ---- add + norm
-        if (so > 1) {
-            FWD(nvh_add_rmsnorm(nullptr, w.residual, md->post_norm[l], w.x, t, h, md->eps, w.slabs, so, stream));
+        bf16* const res = residual_after(l, l);                     // input sites of layers 1..l, post sites of layers 0..l-1
+        const bool interleaved = md->gate_up_inter && md->gate_up_inter[l];
+        if (fuse_post) {
+            FWD(nvh_add_rmsnorm_gemm_bf16_nt(so > 1 ? nullptr : w.y, so > 1 ? w.slabs : nullptr, so > 1 ? so : 0, res, residual_after(l, l + 1),
+                                             md->post_norm[l], md->eps, interleaved ? md->gate_up_inter[l] : md->gate_up_w[l],
+                                             interleaved ? w.act : w.gate_up, interleaved ? md->inter : 2 * md->inter, t, 2 * md->inter, h,
+                                             interleaved ? 1 : 0, stream));
+            if (!interleaved) FWD(nvh_silu_mul(w.gate_up, w.act, t, md->inter, stream));
+        } else if (so > 1) {
+            FWD(nvh_add_rmsnorm(nullptr, res, md->post_norm[l], w.x, t, h, md->eps, w.slabs, so, stream));
         } else {
             if (comm && fused_exchange) {
-                FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->post_norm[l], w.x, t, h, md->eps, stream));
+                FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, res, md->post_norm[l], w.x, t, h, md->eps, stream));
             } else {
                 if (comm) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
-                FWD(nvh_add_rmsnorm(w.y, w.residual, md->post_norm[l], w.x, t, h, md->eps, nullptr, 0, stream));
+                FWD(nvh_add_rmsnorm(w.y, res, md->post_norm[l], w.x, t, h, md->eps, nullptr, 0, stream));
             }
         }
         // ---- MLP
-        if (md->gate_up_inter && md->gate_up_inter[l]) {
+        if (fuse_post) {
+            // (gate/up projected in the launch above)
+        } else if (md->gate_up_inter && md->gate_up_inter[l]) {
             FWD(nvh_gemm_swiglu_bf16_nt(w.x, h, md->gate_up_inter[l], w.act, md->inter, t, 2 * md->inter, h, stream));
         } else {
             FWD(nvh_gemm_bf16_nt(w.x, h, md->gate_up_w[l], nullptr, w.gate_up, 2 * md->inter, t, 2 * md->inter, h, 1, nullptr, stream));
@@ -228,10 +263,11 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
       }
     }
     if (runs(2 * md->layers + 1)) {
+        bf16* const res = residual_after(md->layers - 1, md->layers);
         if (comm && fused_exchange) {
-            FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, w.residual, md->final_norm, hidden_out, t, h, md->eps, stream));
+            FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, res, md->final_norm, hidden_out, t, h, md->eps, stream));
         } else {
-            FWD(nvh_add_rmsnorm(pending_y, w.residual, md->final_norm, hidden_out, t, h, md->eps,
+            FWD(nvh_add_rmsnorm(pending_y, res, md->final_norm, hidden_out, t, h, md->eps,
                                 pending_slabs ? w.slabs : nullptr, pending_count, stream));
         }
     }

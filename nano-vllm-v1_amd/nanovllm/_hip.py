@@ -43,6 +43,8 @@ SIGNATURES = {
     "nvh_splitk_reduce": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     "nvh_gemm_swiglu_bf16_nt": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, vp]),
     "nvh_interleave_gate_up": (i32, [vp, vp, i64, i64, vp]),
+    "nvh_add_rmsnorm_gemm_bf16_nt": (i32, [vp, vp, i64, vp, vp, vp, f32, vp, vp, i64, i64, i64, i64, i32, vp]),
+    "nvh_add_rmsnorm_gemm_fused": (i32, [i64, i64, i64, i64, i32]),
     "nvh_attn_varlen": (i32, [vp, i64, vp, vp, i64, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, f32, vp, i32, vp, vp]),
     "nvh_attn_varlen_workspace_bytes": (i64, [i64, i64, i64, i32]),
     "nvh_attn_varlen_suggest_splits": (i32, [i64, i64, i64, i64, i64]),

@@ -220,6 +220,34 @@ def linear_swiglu(x: torch.Tensor, weight_interleaved: torch.Tensor) -> torch.Te
     return y.view(*x.shape[:-1], n // 2)
 
 
+def add_rmsnorm_linear(x: torch.Tensor | None, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float, weight: torch.Tensor,
+                       partials: torch.Tensor | None = None, swiglu: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
+    """(y, new_residual) of add_rmsnorm followed by linear (or linear_swiglu over an interleaved weight) in ONE launch:
+    decode batches of 1..32 rows with rows of at most 1024 elements.  ``residual`` is NOT modified; bit-identical to the
+    two calls.  ``fused_add_rmsnorm_linear`` tells whether the step executor would take it."""
+    _gpu_bf16(residual, norm_weight, weight)
+    k = residual.shape[-1]
+    m = residual.numel() // k
+    n = weight.shape[0]
+    assert residual.is_contiguous() and weight.is_contiguous() and weight.shape[1] == k
+    new_res = torch.empty_like(residual)
+    y = torch.empty(m, n // 2 if swiglu else n, dtype=BF16, device=residual.device)
+    if partials is not None:
+        assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.shape[-2:] == (m, k)
+        prev, slabs, ns = 0, partials.data_ptr(), partials.shape[0]
+    else:
+        _gpu_bf16(x)
+        x = x.contiguous()
+        prev, slabs, ns = x.data_ptr(), 0, 0
+    _hip.call("nvh_add_rmsnorm_gemm_bf16_nt", prev, slabs, ns, residual.data_ptr(), new_res.data_ptr(), norm_weight.data_ptr(),
+              float(eps), weight.data_ptr(), y.data_ptr(), y.shape[1], m, n, k, 1 if swiglu else 0, _stream())
+    return y, new_res
+
+
+def fused_add_rmsnorm_linear(m: int, n: int, k: int, num_partials: int = 0, swiglu: bool = False) -> bool:
+    return bool(_hip.lib().nvh_add_rmsnorm_gemm_fused(m, n, k, num_partials, 1 if swiglu else 0))
+
+
 def splitk_reduce(partials: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
     s, m, n = partials.shape
     y = torch.empty(m, n, dtype=BF16, device=partials.device)

@@ -299,6 +299,33 @@ int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const void* w, con
     return NVH_OK;
 }
 
+// Residual add + RMSNorm + the projection that consumes it (models/qwen3.py:335-349 between two projections): the two
+// operators above composed, with the new residual written to a second buffer; swiglu != 0: the gate/up epilogue of
+// layers/activation.py:36-58 over rows interleaved in blocks of 16 (gate 16b.. | up 16b..).
+int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* slabs, int64_t num_slabs, const void* residual_in, void* residual_out,
+                                     const void* norm_weight, float eps, const void* w, void* y, int64_t y_row_stride, int64_t M, int64_t N,
+                                     int64_t K, int32_t swiglu, nvh_stream_t) {
+    REQUIRE(residual_in && residual_out && norm_weight && w && y && (prev || slabs), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: null pointer");
+    REQUIRE(residual_in != residual_out, NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: residual_out must not alias residual_in");
+    REQUIRE(M >= 1 && M <= 32 && K >= 64 && K <= 1024 && K % 64 == 0 && N >= 1 && (swiglu ? N % 32 == 0 : N % 4 == 0), NVH_ENOSYS,
+            "nvh_add_rmsnorm_gemm_bf16_nt: %ld x %ld x %ld unsupported", (long)M, (long)N, (long)K);
+    std::memcpy(residual_out, residual_in, (size_t)(M * K) * sizeof(bf16));
+    std::vector<bf16> xn((size_t)(M * K));
+    int32_t rc = nvh_add_rmsnorm(slabs ? nullptr : prev, residual_out, norm_weight, xn.data(), M, K, eps, slabs, slabs ? num_slabs : 0, nullptr);
+    if (rc != NVH_OK) return rc;
+    if (!swiglu) return nvh_gemm_bf16_nt(xn.data(), K, w, nullptr, y, y_row_stride, M, N, K, 1, nullptr, nullptr);
+    std::vector<bf16> gu((size_t)(M * N));
+    rc = nvh_gemm_bf16_nt(xn.data(), K, w, nullptr, gu.data(), N, M, N, K, 1, nullptr, nullptr);
+    if (rc != NVH_OK) return rc;
+    for (int64_t m = 0; m < M; ++m)
+        for (int64_t b = 0; b < N / 32; ++b)
+            for (int64_t j = 0; j < 16; ++j) {
+                const float g = bf2f(gu[(size_t)(m * N + 32 * b + j)]), u = bf2f(gu[(size_t)(m * N + 32 * b + 16 + j)]);
+                ((bf16*)y)[m * y_row_stride + 16 * b + j] = f2bf(round_bf(g / (1.0f + std::exp(-g))) * u);
+            }
+    return NVH_OK;
+}
+
 int32_t nvh_splitk_reduce(const float* partials, int64_t num_partials, const void* bias, void* y, int64_t y_row_stride, int64_t M,
                           int64_t N, nvh_stream_t) {
     REQUIRE(partials && y && num_partials >= 1, NVH_EINVAL, "nvh_splitk_reduce: bad arguments");

@@ -218,6 +218,50 @@ def test_native_executor_equals_operator_modules(eager, modules):
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("batch", [1, 3, 8])
+def test_decode_with_the_norm_inside_the_projection_equals_separate_launches(eager, monkeypatch, batch):
+    """Decode batches fold the residual add + RMSNorm into the prologue of the projection that consumes it (two launches
+    less per layer, the residual alternating between two buffers).  With the previous projection's K-slabs kept
+    (NVH_DECODE_SLABS) the step must give the bits of the separate launches (NVH_NO_NORM_GEMM); the default route (no
+    slabs at all) must agree with the oracle like every other step."""
+    runner, oracle = eager
+    g = torch.Generator().manual_seed(40 + batch)
+    prompts = [torch.randint(0, 1024, (20 + 7 * i,), generator=g).tolist() for i in range(batch)]
+    forced = torch.randint(0, 1024, (3, batch), generator=g).tolist()        # the same next tokens on every route
+    outs = {}
+    for mode in ("default", "slabs", "separate"):
+        monkeypatch.delenv("NVH_DECODE_SLABS", raising=False)
+        monkeypatch.delenv("NVH_NO_NORM_GEMM", raising=False)
+        if mode == "slabs":
+            monkeypatch.setenv("NVH_DECODE_SLABS", "1")
+        if mode == "separate":
+            monkeypatch.setenv("NVH_NO_NORM_GEMM", "1")
+        runner.kv_cache.zero_()
+        seqs = [seq(p, 0, len(p), [i]) for i, p in enumerate(prompts)]
+        logits, _, _ = runner.forward_logits(seqs)
+        steps = []
+        for k in range(3):
+            for s, t in zip(seqs, forced[k]):
+                s.num_cached_tokens += s.num_new_tokens
+                s.append_token(t)
+                s.num_new_tokens = 1
+            logits, _, _ = runner.forward_logits(seqs)
+            steps.append(logits.cpu())
+        outs[mode] = torch.stack(steps)
+    assert torch.equal(outs["slabs"], outs["separate"])
+    oracle.kv.zero_()
+    ob = [M.SeqState(list(p), 0, len(p), [i]) for i, p in enumerate(prompts)]
+    ol, _ = oracle.run(ob)
+    for k in range(3):
+        for s, t in zip(ob, forced[k]):
+            s.num_cached_tokens += s.num_new_tokens
+            s.token_ids.append(t)
+            s.num_new_tokens = 1
+        ol, _ = oracle.run(ob)
+        close(outs["default"][k], ol)
+        close(outs["separate"][k], ol)
+
+
 def test_mixed_step_decode_prefix_matches_oracle_and_unsplit_path():
     """A serving-shaped step: ten running sequences with one token each (contexts that sit on, before and after page
     boundaries), then a continuing chunk and a fresh prompt.  The native executor sends the one-token prefix through

@@ -323,7 +323,8 @@ GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024
                (256, 6144, 1024), (256, 151936, 64), (400, 151936, 128), (400, 50176, 128),   # LM head: 256x256 tile, padded rows; 256x128 tile (two row tiles)
                (5, 26624, 192), (40, 4096, 1024), (64, 7168, 512),         # 16x64 two-wave tile; 64x64 at 33..64 rows
                (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64),   # 256x256 eight-wave tile (full, ragged, one k-tile)
-               (1024, 17408, 128), (512, 35000, 64)]                       # ... whole rounds + a remainder launch on smaller tiles
+               (1024, 17408, 128), (512, 35000, 64),                       # ... whole rounds + a remainder launch on smaller tiles
+               (1, 1024, 2048), (7, 1024, 3072), (17, 1024, 3072), (32, 1000, 2048), (3, 2048, 1536), (16, 1024, 4096)]   # K split between the waves of a workgroup (decode O / down projections)
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -344,6 +345,14 @@ def test_gemm_bias_strided_input_and_splitk(ops):
     for s in (2, 3, 8):
         slabs = ops.linear_splitk(dev(x_wide)[:, :k], dev(w), s)
         assert_gemm(ops.splitk_reduce(slabs, dev(b)), ref)
+
+
+def test_gemm_k_over_waves_bias_and_strided_rows(ops):
+    """Decode-sized batch, narrow output, long K: K is split between the waves of a workgroup; bias and strided input rows."""
+    m, n, k = 9, 1024, 3072
+    x_wide = rnd(m, k + 64, seed=23)
+    w, b = rnd(n, k, seed=24, scale=0.05), rnd(n, seed=25)
+    assert_gemm(ops.linear(dev(x_wide)[:, :k], dev(w), dev(b)), R.linear(x_wide[:, :k], w, b))
 
 
 def test_gemm_bias_across_the_round_cut(ops):
@@ -379,6 +388,49 @@ def test_gemm_swiglu_epilogue_bit_identical_to_separate_kernels(ops, m, inter, k
     fused = ops.linear_swiglu(xd, wi)
     assert_exact(fused, sep.cpu())
     assert_gemm(fused, R.silu_mul(R.linear(x, w)), max_frac=0.05)
+
+
+@pytest.mark.parametrize("m,n,k,slabs,swiglu", [(1, 4096, 1024, 12, False), (1, 6144, 1024, 8, True), (2, 4096, 1024, 0, False),
+                                                (5, 1000, 512, 3, False), (16, 6144, 1024, 0, True), (17, 4096, 1024, 0, False),
+                                                (32, 2048, 1024, 2, True), (9, 96, 64, 5, False), (3, 4096, 960, 2, False)])
+def test_add_rmsnorm_in_the_projection_prologue_bit_identical(ops, m, n, k, slabs, swiglu):
+    """Residual add + RMSNorm + projection in one launch (decode batches) against the two launches: the projection
+    output and the new residual carry the same bits, from a bf16 input or from split-K slabs of the previous projection,
+    plain or with the SwiGLU epilogue; the input residual is left alone; against the oracle within the GEMM tolerance."""
+    prev_in, prev_w = rnd(m, 1024, seed=61), rnd(k, 1024, seed=62, scale=0.05)
+    res, gamma = rnd(m, k, seed=63), (rnd(k, seed=64).float() * 0.1 + 1).to(BF)
+    w = rnd(n, k, seed=65, scale=0.05)
+    wd = dev(w)
+    if swiglu:
+        wd = ops.interleave_gate_up(wd)
+    partials = ops.linear_splitk(dev(prev_in), dev(prev_w), slabs) if slabs else None
+    prev = None if slabs else ops.linear(dev(prev_in), dev(prev_w))
+    res_a = dev(res.clone())
+    xa, res_a = ops.add_rmsnorm(prev, res_a, dev(gamma), 1e-6, partials=partials)
+    ya = ops.linear_swiglu(xa, wd) if swiglu else ops.linear(xa, wd)
+    res_b = dev(res.clone())
+    yb, new_res = ops.add_rmsnorm_linear(prev, res_b, dev(gamma), 1e-6, wd, partials=partials, swiglu=swiglu)
+    assert_exact(yb, ya.cpu())
+    assert_exact(new_res, res_a.cpu())
+    assert_exact(res_b, res)
+    prev_ref = R.linear(prev_in, prev_w)
+    x_ref, _ = R.add_rms_norm(prev_ref, res, gamma, 1e-6)
+    y_ref = R.linear(x_ref, w)
+    assert_gemm(yb, R.silu_mul(y_ref) if swiglu else y_ref, max_frac=0.05)
+
+
+def test_add_rmsnorm_projection_argument_checks(ops):
+    from nanovllm import _hip
+    lib = _hip.lib()
+    a = torch.zeros(4, 1024, dtype=BF, device="cuda")
+    w = torch.zeros(64, 1024, dtype=BF, device="cuda")
+    args = lambda res_out, m, k: (a.data_ptr(), 0, 0, a.data_ptr(), res_out, a.data_ptr(), 1e-6, w.data_ptr(), a.data_ptr(), 64, m, 64, k, 0, 0)
+    assert lib.nvh_add_rmsnorm_gemm_bf16_nt(*args(a.data_ptr(), 4, 1024)) == -22           # residual_out aliases residual_in
+    b = torch.zeros(4, 1024, dtype=BF, device="cuda")
+    assert lib.nvh_add_rmsnorm_gemm_bf16_nt(*args(b.data_ptr(), 33, 1024)) == -38           # too many rows: NVH_ENOSYS
+    assert lib.nvh_add_rmsnorm_gemm_bf16_nt(*args(b.data_ptr(), 4, 2048)) == -38            # rows too wide
+    assert not ops.fused_add_rmsnorm_linear(33, 4096, 1024) and not ops.fused_add_rmsnorm_linear(4, 4096, 5120)
+    assert ops.fused_add_rmsnorm_linear(1, 4096, 1024, 12) and ops.fused_add_rmsnorm_linear(1, 6144, 1024, 8, True)
 
 
 def _paged_case(seed, lens_q, lens_k, hq, hkv, num_pages=40):
