@@ -464,6 +464,8 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     const int n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;                       // this workgroup's rows of the batch: m0 .. m0 + rows - 1
+    const int rows = min(BM, M - m0);
     const int ntiles = K / BK;                            // <= STAGES (checked on the host)
 
     if (wave == PWAVES) {
@@ -519,26 +521,26 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(xv[i][j] * inv)) * bf2f(wv[i][j]));
                 *reinterpret_cast<bf16x8*>(panel + (c >> 3) * (BM * 128) + row * 128 + (((c & 7) ^ ((row >> 1) & 7)) << 4)) = o;
-                if (blockIdx.x == 0) *reinterpret_cast<bf16x8*>(np.res_out + (int64_t)row * K + c * 8) = nr[i];
+                if (blockIdx.x == 0) *reinterpret_cast<bf16x8*>(np.res_out + (int64_t)(m0 + row) * K + c * 8) = nr[i];
             }
         }
     };
     if (np.slabs != nullptr) {
-        for (int row = wave; row < M; row += PWAVES) {
+        for (int row = wave; row < rows; row += PWAVES) {
             float xv[2][8];
             bf16x8 rs[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int c = lane + i * 64;
                 if (c < nchunk) {
-                    rs[i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)row * K + c * 8);
+                    rs[i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)(m0 + row) * K + c * 8);
                     float acc[4][8];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
                     }
-                    const float* src0 = np.slabs + (int64_t)row * K + c * 8;
+                    const float* src0 = np.slabs + (int64_t)(m0 + row) * K + c * 8;
                     const int64_t slab = (int64_t)M * K;
                     int p = 0;
                     for (; p + 4 <= np.num_slabs; p += 4) {
@@ -569,25 +571,25 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
             finish_row(row, xv, rs);
         }
     } else {
-        // up to 32 rows over PWAVES = 8 waves: a wave's rows (at most 4) are all requested before the first is reduced
-        static_assert(PWAVES * 4 >= 32, "rows per wave");
-        bf16x8 pv[4][2], rs[4][2];
+        // BM rows over PWAVES = 8 waves: a wave's rows are all requested before the first is reduced
+        constexpr int RPW = (BM + PWAVES - 1) / PWAVES;
+        bf16x8 pv[RPW][2], rs[RPW][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RPW; ++q) {
             const int row = wave + q * PWAVES;
-            if (row < M) {
+            if (row < rows) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int c = min(lane + i * 64, nchunk - 1);
-                    pv[q][i] = *reinterpret_cast<const bf16x8*>(np.prev + (int64_t)row * K + c * 8);
-                    rs[q][i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)row * K + c * 8);
+                    pv[q][i] = *reinterpret_cast<const bf16x8*>(np.prev + (int64_t)(m0 + row) * K + c * 8);
+                    rs[q][i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)(m0 + row) * K + c * 8);
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < RPW; ++q) {
             const int row = wave + q * PWAVES;
-            if (row < M) {
+            if (row < rows) {
                 float xv[2][8];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
             }
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                const int r = min(wm * WM + j * 16 + fr, M - 1);       // rows past the batch shadow its last row
+                const int r = min(wm * WM + j * 16 + fr, rows - 1);    // rows past the batch shadow its last row
                 bfr[j] = *reinterpret_cast<const bf16x8*>(b_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
             const int col = (n >> 5) * 16 + fq * 4;
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                const int m = wm * WM + j * 16 + fr;
+                const int m = m0 + wm * WM + j * 16 + fr;
                 if (m >= M) continue;
                 bf16x4 o;
 #pragma unroll
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
             if (n >= N) continue;
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
-                const int m = wm * WM + j * 16 + fr;
+                const int m = m0 + wm * WM + j * 16 + fr;
                 if (m >= M) continue;
                 bf16x4 o;
 #pragma unroll
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
 // rows (LDS-DMA, 128-B rows, the ring's swizzle) and the matching x fragments (global -> registers) up front, waits once,
 // multiplies, and the partial tiles meet in LDS: ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)), one bf16 rounding.
 // No barrier until that sum: a wave reads only what it requested itself.
-template <int TM, int KW>
+template <int KW>
 __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, int M, int N, int K) {
@@ -690,7 +692,8 @@ __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * 16;
+    constexpr int TM = 1;                                 // one 16-row tile of the batch per workgroup (blockIdx.y)
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     const int ntiles = K / BK;
     const int per = (ntiles + KW - 1) / KW;               // <= MAXT (checked on the host)
     const int t0 = wave * per, t1 = min(ntiles, t0 + per);
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     bf16x8 xf[TM][MAXT][2];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const bf16* xrow = x + (int64_t)min(j * 16 + fr, M - 1) * x_stride + fq * 8;
+        const bf16* xrow = x + (int64_t)min(m0 + j * 16 + fr, M - 1) * x_stride + fq * 8;
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {
             if (t0 + i < t1) {
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     f32x4 tot;
     if constexpr (KW == 8) tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     else tot = (s[0] + s[1]) + (s[2] + s[3]);
-    const int n = n0 + fq * 4, m = j * 16 + fr;
+    const int n = n0 + fq * 4, m = m0 + j * 16 + fr;
     if (n < N && m < M) {
         bf16x4 o;
 #pragma unroll
@@ -947,22 +950,24 @@ static bool takes_kwaves(const GemmArgs& a) {
     return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= 32 && a.K >= 1536 && a.K <= 4096 &&
            nvh_cdiv(a.N, 32) < 96;
 }
-template <int TM, int KW>
+template <int KW>
 static void launch_kwaves(const GemmArgs& a) {
-    auto kern = gemm_kwaves_bf16_nt_kernel<TM, KW>;
+    constexpr int TM = 1;
+    auto kern = gemm_kwaves_bf16_nt_kernel<KW>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KW * 8 * 2048 + KW * TM * 1024);
         configured = true;
     }
     const int per = (int)nvh_cdiv(a.K / BK, KW);
-    kern<<<(unsigned)nvh_cdiv(a.N, 16), 64 * KW, KW * per * 2048 + KW * TM * 1024, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M, a.N, a.K);
+    kern<<<dim3((unsigned)nvh_cdiv(a.N, 16), (unsigned)nvh_cdiv(a.M, 16)), 64 * KW, KW * per * 2048 + KW * TM * 1024, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M,
+                                                                                                                          a.N, a.K);
 }
 
 static int32_t dispatch_gemm(const GemmArgs& a) {
     if (takes_kwaves(a)) {
-        if (a.K / BK >= 32) { if (a.M <= 16) launch_kwaves<1, 8>(a); else launch_kwaves<2, 8>(a); }
-        else { if (a.M <= 16) launch_kwaves<1, 4>(a); else launch_kwaves<2, 4>(a); }
+        if (a.K / BK >= 32) launch_kwaves<8>(a);
+        else launch_kwaves<4>(a);
         NVH_CHECK_LAUNCH("gemm_kwaves_bf16_nt");
         return NVH_OK;
     }
@@ -1127,7 +1132,7 @@ void launch_gemm_addnorm(const NormPrologue& np, const bf16* w, bf16* y, int64_t
         configured = true;
     }
     const int smem = STAGES * BN * 128 + BM * K * 2;
-    kern<<<(unsigned)nvh_cdiv(N, BN), 64 * 9, smem, st>>>(np, w, y, ys, M, N, K);
+    kern<<<dim3((unsigned)nvh_cdiv(N, BN), (unsigned)nvh_cdiv(M, BM)), 64 * 9, smem, st>>>(np, w, y, ys, M, N, K);
 }
 }  // namespace
 
@@ -1158,9 +1163,12 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* s
                     slabs ? (int)num_slabs : 0};
     hipStream_t st = (hipStream_t)stream;
     // 16 stages = every k-tile of a 1024-wide row
-    if (swiglu) launch_gemm_addnorm<32, 32, 1, 2, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
-    else if (M <= 16) launch_gemm_addnorm<16, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
-    else launch_gemm_addnorm<32, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    // 16 rows per workgroup (17..32 rows: two row tiles, so that no workgroup derives more than 16 rows) while the grid
+    // stays within one workgroup per CU (96 KB of LDS each); the gate/up projection of 17..32 rows would not (2 x 192
+    // workgroups) and keeps all its rows in one
+    if (swiglu && M > 16 && nvh_cdiv(N, 32) * 2 > 256) launch_gemm_addnorm<32, 32, 1, 2, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    else if (swiglu) launch_gemm_addnorm<16, 32, 1, 1, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    else launch_gemm_addnorm<16, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     NVH_CHECK_LAUNCH("gemm_addnorm_bf16_nt");
     return NVH_OK;
 }

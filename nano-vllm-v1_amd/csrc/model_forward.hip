@@ -121,7 +121,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     // decode batches whose add + norm happens in the next projection's prologue: no slabs either (every workgroup of
     // that projection would sum them again); the O / down projections then split K between the waves of a workgroup
     const bool no_full_k = getenv("NVH_DECODE_SLABS") != nullptr;                 // A/B switch for measurements and tests (read per call)
-    const bool full_k = !no_full_k && t <= 16 && !md->comm && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, 0, 0);
+    const bool full_k = !no_full_k && t <= 32 && !md->comm && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, 0, 0);
     const int32_t so = sharded || full_k ? 1 : split_for(t, h, qsz), sd = sharded || full_k ? 1 : split_for(t, h, md->inter);
     auto runs = [&](int part) { return part >= first_part && part <= last_part; };
     const int32_t sq = split_for_qkv(t, qkv_n, h);
