@@ -441,13 +441,13 @@ struct NormPrologue {
     int num_slabs;
 };
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool SWIGLU>
-__global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool SWIGLU, int LW = 1>
+__global__ __launch_bounds__(64 * (8 + LW)) void gemm_addnorm_bf16_nt_kernel(
     NormPrologue np, const bf16* __restrict__ w, bf16* __restrict__ y, int64_t y_stride, int M, int N, int K) {
-    // Nine waves: eight normalise rows (row r goes to wave r mod 8), the first WAVES_N x WAVES_M of them then multiply,
-    // and the ninth does nothing but request the workgroup's weight slice (every k-tile has a stage of its own:
-    // K <= 64 STAGES) and wait for it tile by tile.  A wave's loads retire in order, so a wave that requested both would
-    // see its rows only after the whole slice had landed.
+    // 8 + LW waves: eight normalise rows (row r goes to wave r mod 8), the first WAVES_N x WAVES_M of them then multiply,
+    // and the last LW (one; two for 64-column tiles) do nothing but request the workgroup's weight slice (every k-tile
+    // has a stage of its own: K <= 64 STAGES) and wait for it tile by tile.  A wave's loads retire in order, so a wave
+    // that requested both would see its rows only after the whole slice had landed.
     constexpr int NW = WAVES_N * WAVES_M;
     constexpr int PWAVES = 8;                             // waves that normalise rows; the first NW of them go on to multiply
     static_assert(NW <= PWAVES, "compute waves are prologue waves");
@@ -456,7 +456,8 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
     static_assert(TN >= 1 && TM >= 1, "wave tile");
     constexpr int A_BYTES = BN * 128;
     constexpr int A_GROUPS = BN / 8;                      // 8-row x 128-B pieces = one DMA each
-    static_assert(A_GROUPS * (STAGES - 1) < 64, "the loader's tiles in flight must fit the 6-bit vmcnt");
+    constexpr int LP = A_GROUPS / LW;                     // pieces of a k-tile per loader wave
+    static_assert(A_GROUPS % LW == 0 && LP * (STAGES - 1) < 64, "a loader's tiles in flight must fit the 6-bit vmcnt");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* panel = smem + STAGES * A_BYTES;                // [K / 64][BM][128 B]
 
@@ -468,21 +469,22 @@ __global__ __launch_bounds__(64 * 9) void gemm_addnorm_bf16_nt_kernel(
     const int rows = min(BM, M - m0);
     const int ntiles = K / BK;                            // <= STAGES (checked on the host)
 
-    if (wave == PWAVES) {
+    if (wave >= PWAVES) {
         const int dma_r = lane >> 3, dma_pos = lane & 7;
-        const bf16* src_row[A_GROUPS];
+        const int first = (wave - PWAVES) * LP;           // this loader's pieces: first .. first + LP - 1 of every k-tile
+        const bf16* src_row[LP];
 #pragma unroll
-        for (int p = 0; p < A_GROUPS; ++p) {
-            const int r = p * 8 + dma_r;
+        for (int p = 0; p < LP; ++p) {
+            const int r = (first + p) * 8 + dma_r;
             src_row[p] = w + (int64_t)min(n0 + r, N - 1) * K + (dma_pos ^ ((r >> 1) & 7)) * 8;
         }
         for (int t = 0; t < ntiles; ++t) {
 #pragma unroll
-            for (int p = 0; p < A_GROUPS; ++p)
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[p] + t * BK), (LDS_AS void*)(smem + t * A_BYTES + p * 1024), 16, 0, 2);
+            for (int p = 0; p < LP; ++p)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[p] + t * BK), (LDS_AS void*)(smem + t * A_BYTES + (first + p) * 1024), 16, 0, 2);
         }
         for (int t = 0; t < ntiles; ++t) {
-            wait_tiles_in_flight<A_GROUPS, STAGES - 1>(ntiles - 1 - t);      // tile t has landed
+            wait_tiles_in_flight<LP, STAGES - 1>(ntiles - 1 - t);            // this loader's pieces of tile t have landed
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1123,16 +1125,16 @@ extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, 
 
 // ---- residual add + RMSNorm + projection in one launch (decode batches)
 namespace {
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool SWIGLU>
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool SWIGLU, int LW = 1>
 void launch_gemm_addnorm(const NormPrologue& np, const bf16* w, bf16* y, int64_t ys, int M, int N, int K, hipStream_t st) {
-    auto kern = gemm_addnorm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, SWIGLU>;
+    auto kern = gemm_addnorm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, SWIGLU, LW>;
     static bool configured = false;
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * BN * 128 + BM * 1024 * 2);
         configured = true;
     }
     const int smem = STAGES * BN * 128 + BM * K * 2;
-    kern<<<dim3((unsigned)nvh_cdiv(N, BN), (unsigned)nvh_cdiv(M, BM)), 64 * 9, smem, st>>>(np, w, y, ys, M, N, K);
+    kern<<<dim3((unsigned)nvh_cdiv(N, BN), (unsigned)nvh_cdiv(M, BM)), 64 * (8 + LW), smem, st>>>(np, w, y, ys, M, N, K);
 }
 }  // namespace
 
@@ -1164,9 +1166,11 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* s
     hipStream_t st = (hipStream_t)stream;
     // 16 stages = every k-tile of a 1024-wide row
     // 16 rows per workgroup (17..32 rows: two row tiles, so that no workgroup derives more than 16 rows) while the grid
-    // stays within one workgroup per CU (96 KB of LDS each); the gate/up projection of 17..32 rows would not (2 x 192
-    // workgroups) and keeps all its rows in one
-    if (swiglu && M > 16 && nvh_cdiv(N, 32) * 2 > 256) launch_gemm_addnorm<32, 32, 1, 2, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    // stays within one workgroup per CU (its LDS holds the whole weight slice); the gate/up projection of 17..32 rows
+    // would not with 32-column tiles (2 x 192 workgroups) and takes 64-column ones with two loader waves
+    static const bool no_wide = getenv("NVH_NORM_GEMM_NO_64") != nullptr;            // A/B switch for measurements
+    if (swiglu && M > 16 && nvh_cdiv(N, 32) * 2 > 256 && !no_wide) launch_gemm_addnorm<16, 64, 2, 1, 16, true, 2>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    else if (swiglu && M > 16 && nvh_cdiv(N, 32) * 2 > 256) launch_gemm_addnorm<32, 32, 1, 2, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     else if (swiglu) launch_gemm_addnorm<16, 32, 1, 1, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     else launch_gemm_addnorm<16, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     NVH_CHECK_LAUNCH("gemm_addnorm_bf16_nt");
