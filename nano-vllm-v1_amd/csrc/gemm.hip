@@ -690,7 +690,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, int M, int N, int K) {
     static_assert(KW == 4 || KW == 8, "four or eight waves over K");
-    constexpr int MAXT = 8;                               // k-tiles per wave (K <= 64 * KW * MAXT)
+    constexpr int MAXT = 9;                               // k-tiles per wave (K <= 64 * KW * MAXT)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -946,11 +946,17 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
     return dispatch_gemm(a);
 }
 
-// Decode batches, narrow output, long K (the O / down projections): gemm_kwaves_bf16_nt_kernel.
+// Decode batches and an output narrow enough that 16-column workgroups (x 16-row tiles of the batch) stay within about
+// a round and a half of the chip: gemm_kwaves_bf16_nt_kernel.  The O / down projections of a decode step and their
+// tensor-parallel shards, which cannot hand K-slabs to a consumer (measured against the generic tiles, N = 1024 / 2048 /
+// 5120 at 1..32 rows: 2.2-8.7 us against 2.8-19 us for K = 256..4096; N = 5120 at 32 rows, 640 workgroups: slower).
+// Only from K = 1536: below that a gate/up projection could take it, and its sum over K would no longer be the one of the
+// SwiGLU kernel (nvh_gemm_swiglu_bf16_nt promises the bits of nvh_gemm_bf16_nt + nvh_silu_mul).
 static bool takes_kwaves(const GemmArgs& a) {
     static const bool off = getenv("NVH_NO_KWAVES") != nullptr;                   // A/B switch for measurements
-    return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= 32 && a.K >= 1536 && a.K <= 4096 &&
-           nvh_cdiv(a.N, 32) < 96;
+    static const int kmin = getenv("NVH_KWAVES_KMIN") ? atoi(getenv("NVH_KWAVES_KMIN")) : 1536;   // tuning switch
+    return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= 32 && a.K >= kmin && a.K <= 64 * 8 * 9 &&
+           nvh_cdiv(a.N, 16) * nvh_cdiv(a.M, 16) <= 384;
 }
 template <int KW>
 static void launch_kwaves(const GemmArgs& a) {
@@ -958,7 +964,7 @@ static void launch_kwaves(const GemmArgs& a) {
     auto kern = gemm_kwaves_bf16_nt_kernel<KW>;
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KW * 8 * 2048 + KW * TM * 1024);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KW * 9 * 2048 + KW * TM * 1024);
         configured = true;
     }
     const int per = (int)nvh_cdiv(a.K / BK, KW);
