@@ -201,6 +201,43 @@ def test_fused_qkv_epilogue_route_equals_two_launch_route(eager, tokens):
     greedy_agrees(b, a)
 
 
+@pytest.mark.parametrize("batch", [1, 5, 16, 27])
+def test_decode_prologue_fusion_at_full_size(eager, monkeypatch, batch):
+    """Decode steps of 1..32 sequences at the real shape (rows of 1024: sixteen k-tiles resident per workgroup, 128 and
+    96..192 column tiles, two row tiles from 17 rows): the residual add + RMSNorm inside the QKV and gate/up projections
+    with K-slabs kept gives the bits of the separate launches; the default route (O / down projections over the waves
+    of a workgroup, no slabs) stays within the logits tolerance of them and picks the same greedy ids up to ties."""
+    ps = prompts([40 + 7 * i for i in range(batch)], 50 + batch)
+    g = torch.Generator().manual_seed(7)
+    forced = torch.randint(0, 10000, (2, batch), generator=g).tolist()
+    outs = {}
+    for mode in ("default", "slabs", "separate"):
+        monkeypatch.delenv("NVH_DECODE_SLABS", raising=False)
+        monkeypatch.delenv("NVH_NO_NORM_GEMM", raising=False)
+        if mode == "slabs":
+            monkeypatch.setenv("NVH_DECODE_SLABS", "1")
+        if mode == "separate":
+            monkeypatch.setenv("NVH_NO_NORM_GEMM", "1")
+        eager.kv_cache.zero_()
+        seqs = [seq(p, 0, len(p), [i]) for i, p in enumerate(ps)]
+        eager.forward_logits(seqs)
+        steps = []
+        for k in range(2):
+            for s_, t in zip(seqs, forced[k]):
+                s_.num_cached_tokens += s_.num_new_tokens
+                s_.append_token(t)
+                s_.num_new_tokens = 1
+            logits, _, _ = eager.forward_logits(seqs)
+            steps.append(logits.cpu())
+        outs[mode] = torch.stack(steps)
+    if batch <= 2:                                   # beyond two rows the executor does not take the slab form by itself
+        assert torch.equal(outs["slabs"], outs["separate"])
+    else:
+        close(outs["slabs"].flatten(0, 1), outs["separate"].flatten(0, 1))
+    close(outs["default"].flatten(0, 1), outs["separate"].flatten(0, 1))
+    greedy_agrees(outs["separate"].flatten(0, 1), outs["default"].flatten(0, 1))
+
+
 def test_kv_pool_sized_from_free_memory():
     """num_kvcache_blocks <= 0 (the reference's only mode, engine/model_runner.py:319-375): the pool takes what
     gpu_memory_utilization leaves after the weights and the peak activations of the warm-up step, and the count is
