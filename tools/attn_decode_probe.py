@@ -27,3 +27,14 @@ for rep in range(3):
     t = timeit(lambda i: ops.attn_decode(q, kc, vc, lens, bts[i % sets], d ** -0.5, num_splits=sp), iters=48)
     byts = b * ctx * hkv * d * 2 * 2
     print(f"B={b} ctx={ctx} splits={sp}: {t:7.2f} us  {byts / t / 1e3:7.0f} GB/s  checksum {float(ref.abs().sum()):.3f}", flush=True)
+# the fused form the decode graph replays: raw qkv rows in, q/k norm + RoPE + KV store of the new token inside the launch
+qkv = torch.randn(b, (hq + 2 * hkv) * d, device="cuda", dtype=BF)
+qw = torch.ones(d, device="cuda", dtype=BF)
+kw = torch.ones(d, device="cuda", dtype=BF)
+pos = torch.full((b,), ctx - 1, dtype=torch.int64, device="cuda")
+half = torch.arange(64, dtype=torch.float32) / 64
+ang = torch.arange(ctx + 8, dtype=torch.float32)[:, None] * (1e6 ** -half)[None, :]
+cs = torch.cat([ang.cos(), ang.sin()], -1).contiguous().cuda()
+for rep in range(3):
+    t = timeit(lambda i: ops.attn_decode_fused_qkv(qkv, hq, hkv, qw, kw, 1e-6, pos, cs, kc, vc, lens, bts[i % sets], d ** -0.5, num_splits=sp), iters=48)
+    print(f"fused  B={b} ctx={ctx} splits={sp}: {t:7.2f} us  {byts / t / 1e3:7.0f} GB/s", flush=True)
