@@ -955,7 +955,7 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
 static bool takes_kwaves(const GemmArgs& a) {
     static const bool off = getenv("NVH_NO_KWAVES") != nullptr;                   // A/B switch for measurements
     static const int kmin = getenv("NVH_KWAVES_KMIN") ? atoi(getenv("NVH_KWAVES_KMIN")) : 1536;   // tuning switch
-    return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= 32 && a.K >= kmin && a.K <= 64 * 8 * 9 &&
+    return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= (getenv("NVH_NORM_GEMM_ROWS") ? 64 : 32) && a.K >= kmin && a.K <= 64 * 8 * 9 &&
            nvh_cdiv(a.N, 16) * nvh_cdiv(a.M, 16) <= 384;
 }
 template <int KW>
@@ -1148,9 +1148,17 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_fused(int64_t M, int64_t N, int64_t K, i
     const bool off = getenv("NVH_NO_NORM_GEMM") != nullptr;                        // A/B switch for measurements and tests (read per call)
     // KB a workgroup reads to derive the rows again (every workgroup of the grid does): beyond this the norm launch is cheaper
     static const int64_t budget_kb = getenv("NVH_NORM_GEMM_KB") ? atoll(getenv("NVH_NORM_GEMM_KB")) : 128;
-    if (off || M < 1 || M > 32 || K < BK || K > 1024 || K % BK != 0 || N < 1 || N >= (1 << 30) || num_slabs < 0 || num_slabs > 64) return 0;
+    // Rows a caller is advised to bring.  The kernels take up to 64 (33..64 rows measured 2.6-3.7 % faster per decode step:
+    // 2.12 / 2.22 / 2.39 ms against 2.17 / 2.29 / 2.48 ms at 40 / 48 / 64 sequences), the default stays at 32: every
+    // row count that changes route changes the order of a few fp32 sums, and serving steps of 33..64 tokens are mostly
+    // mixed ones whose neighbours take the generic route.
+    static const int64_t max_rows = getenv("NVH_NORM_GEMM_ROWS") ? atoll(getenv("NVH_NORM_GEMM_ROWS")) : 32;
+    if (off || M < 1 || M > 64 || M > max_rows || K < BK || K > 1024 || K % BK != 0 || N < 1 || N >= (1 << 30) || num_slabs < 0 || num_slabs > 64) return 0;
     if (swiglu ? N % 32 != 0 : N % 4 != 0) return 0;
-    const int64_t kb = M * (num_slabs > 0 ? num_slabs * 4 * K : 2 * K) / 1024;
+    // one workgroup per CU (its LDS holds the whole weight slice): beyond 32 rows only grids of one round
+    if (M > 32 && nvh_cdiv(N, 64) * nvh_cdiv(M, 16) > 256) return 0;
+    const int64_t rows = M < 16 ? M : 16;                                          // per workgroup
+    const int64_t kb = rows * (num_slabs > 0 ? num_slabs * 4 * K : 2 * K) / 1024;
     return kb <= budget_kb;
 }
 
@@ -1164,20 +1172,20 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* s
                     (slabs ? nvh_aligned16(slabs) : nvh_aligned16(prev)) && ((uintptr_t)y & 7) == 0 && y_row_stride % 4 == 0,
                 NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: alignment");
     NVH_REQUIRE(!slabs || (num_slabs >= 1 && num_slabs <= 64), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: num_slabs %ld out of range", (long)num_slabs);
-    NVH_REQUIRE(M >= 1 && M <= 32 && K >= BK && K <= 1024 && K % BK == 0 && N >= 1 && N < (1 << 30) && (swiglu ? N % 32 == 0 : N % 4 == 0),
-                NVH_ENOSYS, "nvh_add_rmsnorm_gemm_bf16_nt: %ld x %ld x %ld unsupported (1..32 rows, K a multiple of 64 up to 1024; ask nvh_add_rmsnorm_gemm_fused)",
+    NVH_REQUIRE(M >= 1 && M <= 64 && K >= BK && K <= 1024 && K % BK == 0 && N >= 1 && N < (1 << 30) && (swiglu ? N % 32 == 0 : N % 4 == 0),
+                NVH_ENOSYS, "nvh_add_rmsnorm_gemm_bf16_nt: %ld x %ld x %ld unsupported (1..64 rows, K a multiple of 64 up to 1024; ask nvh_add_rmsnorm_gemm_fused)",
                 (long)M, (long)N, (long)K);
     NormPrologue np{(const bf16*)prev, slabs, (const bf16*)residual_in, (bf16*)residual_out, (const bf16*)norm_weight, eps,
                     slabs ? (int)num_slabs : 0};
     hipStream_t st = (hipStream_t)stream;
-    // 16 stages = every k-tile of a 1024-wide row
-    // 16 rows per workgroup (17..32 rows: two row tiles, so that no workgroup derives more than 16 rows) while the grid
-    // stays within one workgroup per CU (its LDS holds the whole weight slice); the gate/up projection of 17..32 rows
-    // would not with 32-column tiles (2 x 192 workgroups) and takes 64-column ones with two loader waves
-    static const bool no_wide = getenv("NVH_NORM_GEMM_NO_64") != nullptr;            // A/B switch for measurements
-    if (swiglu && M > 16 && nvh_cdiv(N, 32) * 2 > 256 && !no_wide) launch_gemm_addnorm<16, 64, 2, 1, 16, true, 2>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
-    else if (swiglu && M > 16 && nvh_cdiv(N, 32) * 2 > 256) launch_gemm_addnorm<32, 32, 1, 2, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    // 16 stages = every k-tile of a 1024-wide row.  16 rows per workgroup (more rows: row tiles, so that no workgroup
+    // derives more than 16 rows) while the grid stays within one workgroup per CU (its LDS holds the whole weight
+    // slice): 32-column tiles while they fit one round, else 64-column ones fed by two loader waves (the gate/up
+    // projection at 17..32 rows, the QKV projection at 33..64)
+    const bool wide = nvh_cdiv(N, 32) * nvh_cdiv(M, 16) > 256;
+    if (swiglu && wide) launch_gemm_addnorm<16, 64, 2, 1, 16, true, 2>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     else if (swiglu) launch_gemm_addnorm<16, 32, 1, 1, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    else if (wide) launch_gemm_addnorm<16, 64, 2, 1, 16, false, 2>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     else launch_gemm_addnorm<16, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     NVH_CHECK_LAUNCH("gemm_addnorm_bf16_nt");
     return NVH_OK;

@@ -35,7 +35,7 @@ Workspace carve(const nvh_qwen3_model* md, int64_t t, int64_t b, int32_t decode_
     int64_t off = 0;
     auto take = [&](int64_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
     w.residual = (bf16*)take(t * h * 2);
-    w.residual2 = (bf16*)take((t <= 32 ? t : 0) * h * 2);   // decode batches: the residual alternates between two buffers (see forward_impl)
+    w.residual2 = (bf16*)take((t <= 64 ? t : 0) * h * 2);   // decode batches: the residual alternates between two buffers (see forward_impl)
     w.x = (bf16*)take(t * h * 2);
     w.y = (bf16*)take(t * h * 2);
     w.qkv = (bf16*)take(t * (qsz + 2 * kvsz) * 2);
@@ -121,7 +121,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     // decode batches whose add + norm happens in the next projection's prologue: no slabs either (every workgroup of
     // that projection would sum them again); the O / down projections then split K between the waves of a workgroup
     const bool no_full_k = getenv("NVH_DECODE_SLABS") != nullptr;                 // A/B switch for measurements and tests (read per call)
-    const bool full_k = !no_full_k && t <= 32 && !md->comm && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, 0, 0);
+    const bool full_k = !no_full_k && t <= 64 && !md->comm && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, 0, 0);
     const int32_t so = sharded || full_k ? 1 : split_for(t, h, qsz), sd = sharded || full_k ? 1 : split_for(t, h, md->inter);
     auto runs = [&](int part) { return part >= first_part && part <= last_part; };
     const int32_t sq = split_for_qkv(t, qkv_n, h);
@@ -150,8 +150,8 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     // buffer and writes it to the other, so the residual stream alternates between w.residual and w.residual2; which
     // one holds it follows from the number of fused sites passed (the same for every layer, so a step cut into
     // parts agrees with itself).
-    const bool fuse_in = !comm && t <= 32 && sq == 1 && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, pending_count, 0);
-    const bool fuse_post = !comm && t <= 32 && nvh_add_rmsnorm_gemm_fused(t, 2 * md->inter, h, so > 1 ? so : 0, 1) &&
+    const bool fuse_in = !comm && t <= 64 && sq == 1 && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, pending_count, 0);
+    const bool fuse_post = !comm && t <= 64 && nvh_add_rmsnorm_gemm_fused(t, 2 * md->inter, h, so > 1 ? so : 0, 1) &&
                            nvh_add_rmsnorm_gemm_fused(t, 2 * md->inter, h, so > 1 ? so : 0, 0);
     auto residual_after = [&](int in_sites, int post_sites) {
         const int swaps = (fuse_in ? in_sites : 0) + (fuse_post ? post_sites : 0);

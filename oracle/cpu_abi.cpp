@@ -307,7 +307,7 @@ int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* slabs, int64
                                      int64_t K, int32_t swiglu, nvh_stream_t) {
     REQUIRE(residual_in && residual_out && norm_weight && w && y && (prev || slabs), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: null pointer");
     REQUIRE(residual_in != residual_out, NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: residual_out must not alias residual_in");
-    REQUIRE(M >= 1 && M <= 32 && K >= 64 && K <= 1024 && K % 64 == 0 && N >= 1 && (swiglu ? N % 32 == 0 : N % 4 == 0), NVH_ENOSYS,
+    REQUIRE(M >= 1 && M <= 64 && K >= 64 && K <= 1024 && K % 64 == 0 && N >= 1 && (swiglu ? N % 32 == 0 : N % 4 == 0), NVH_ENOSYS,
             "nvh_add_rmsnorm_gemm_bf16_nt: %ld x %ld x %ld unsupported", (long)M, (long)N, (long)K);
     std::memcpy(residual_out, residual_in, (size_t)(M * K) * sizeof(bf16));
     std::vector<bf16> xn((size_t)(M * K));

@@ -166,7 +166,7 @@ def test_add_rmsnorm_inside_the_projection(cpu, f1):
     assert cpu.nvh_add_rmsnorm_gemm_bf16_nt(x.data_ptr(), None, 0, r_in.data_ptr(), r_in.data_ptr(), g.data_ptr(), 1e-6, w.data_ptr(),
                                            y.data_ptr(), n, m, n, k, 0, None) == -22
     assert cpu.nvh_add_rmsnorm_gemm_bf16_nt(x.data_ptr(), None, 0, r_in.data_ptr(), r_out.data_ptr(), g.data_ptr(), 1e-6, w.data_ptr(),
-                                           y.data_ptr(), n, 33, n, k, 0, None) == -38
+                                           y.data_ptr(), n, 65, n, k, 0, None) == -38
 
 
 def test_qk_epilogue_and_cache_store(cpu):

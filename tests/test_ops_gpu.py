@@ -325,7 +325,7 @@ GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024
                (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64),   # 256x256 eight-wave tile (full, ragged, one k-tile)
                (1024, 17408, 128), (512, 35000, 64),                       # ... whole rounds + a remainder launch on smaller tiles
                (1, 1024, 2048), (7, 1024, 3072), (17, 1024, 3072), (32, 1000, 2048), (3, 2048, 1536), (16, 1024, 4096),   # K split between the waves of a workgroup (decode O / down projections)
-               (8, 5120, 1600), (16, 5120, 4352), (32, 2048, 3200)]   # ... wider outputs, K up to 4608
+               (8, 5120, 1600), (16, 5120, 4352), (32, 2048, 3200), (64, 1024, 3072), (47, 1024, 2048)]   # ... wider outputs, K up to 4608, up to 64 rows
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -394,7 +394,8 @@ def test_gemm_swiglu_epilogue_bit_identical_to_separate_kernels(ops, m, inter, k
 @pytest.mark.parametrize("m,n,k,slabs,swiglu", [(1, 4096, 1024, 12, False), (1, 6144, 1024, 8, True), (2, 4096, 1024, 0, False),
                                                 (5, 1000, 512, 3, False), (16, 6144, 1024, 0, True), (17, 4096, 1024, 0, False),
                                                 (32, 2048, 1024, 2, True), (9, 96, 64, 5, False), (3, 4096, 960, 2, False),
-                                                (32, 6144, 1024, 0, True), (21, 6144, 1024, 3, True), (29, 4096, 1024, 0, False)])   # 17..32 rows: row tiles of 16; 64-column tiles with two loader waves
+                                                (32, 6144, 1024, 0, True), (21, 6144, 1024, 3, True), (29, 4096, 1024, 0, False),
+                                                (64, 4096, 1024, 0, False), (45, 2048, 512, 0, True), (50, 4096, 1024, 0, False)])   # 17..32 rows: row tiles of 16; 64-column tiles with two loader waves
 def test_add_rmsnorm_in_the_projection_prologue_bit_identical(ops, m, n, k, slabs, swiglu):
     """Residual add + RMSNorm + projection in one launch (decode batches) against the two launches: the projection
     output and the new residual carry the same bits, from a bf16 input or from split-K slabs of the previous projection,
@@ -429,9 +430,10 @@ def test_add_rmsnorm_projection_argument_checks(ops):
     args = lambda res_out, m, k: (a.data_ptr(), 0, 0, a.data_ptr(), res_out, a.data_ptr(), 1e-6, w.data_ptr(), a.data_ptr(), 64, m, 64, k, 0, 0)
     assert lib.nvh_add_rmsnorm_gemm_bf16_nt(*args(a.data_ptr(), 4, 1024)) == -22           # residual_out aliases residual_in
     b = torch.zeros(4, 1024, dtype=BF, device="cuda")
-    assert lib.nvh_add_rmsnorm_gemm_bf16_nt(*args(b.data_ptr(), 33, 1024)) == -38           # too many rows: NVH_ENOSYS
+    assert lib.nvh_add_rmsnorm_gemm_bf16_nt(*args(b.data_ptr(), 65, 1024)) == -38           # too many rows: NVH_ENOSYS
     assert lib.nvh_add_rmsnorm_gemm_bf16_nt(*args(b.data_ptr(), 4, 2048)) == -38            # rows too wide
-    assert not ops.fused_add_rmsnorm_linear(33, 4096, 1024) and not ops.fused_add_rmsnorm_linear(4, 4096, 5120)
+    assert not ops.fused_add_rmsnorm_linear(65, 4096, 1024) and not ops.fused_add_rmsnorm_linear(4, 4096, 5120)
+    assert not ops.fused_add_rmsnorm_linear(48, 4096, 1024)      # the kernels take up to 64 rows, callers are advised to stop at 32
     assert ops.fused_add_rmsnorm_linear(1, 4096, 1024, 12) and ops.fused_add_rmsnorm_linear(1, 6144, 1024, 8, True)
 
 
