@@ -451,12 +451,18 @@ extern "C" int64_t nvh_attn_decode_workspace_bytes(int64_t batch, int64_t num_q_
 }
 
 extern "C" int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_heads, int64_t max_context) {
-    // Aim for >= 512 workgroups (2 per CU) while keeping >= 128 keys per range.
-    const int64_t wgs = batch * num_kv_heads;
-    int64_t want = nvh_cdiv(512, wgs > 0 ? wgs : 1);
+    // Aim for >= 512 workgroups (2 per CU) while keeping >= 128 keys per range at the longest context, at most 32 ranges,
+    // and none once every CU has a workgroup anyway.  Measured on Qwen3-0.6B decode steps at ~1040 keys (ms per step by
+    // the workgroup count aimed for, 256 / 512 / 1024 / 2048): 1 sequence 0.90 / 0.92 (64 ranges offered; 0.90 with 32)
+    // / - / -, 8 sequences 1.13 / 1.15 / 1.17 / 1.31, 16 sequences 1.43 / 1.39 / 1.50 / 1.60, 32 sequences 1.70 (one
+    // range, no merge launch) / 1.73 / 1.81 / 1.93: every range costs a workgroup's prologue and a record for the merge,
+    // every range less a longer chain of dependent trips.
+    static const int64_t target = getenv("NVH_DECODE_TARGET_WGS") ? atoll(getenv("NVH_DECODE_TARGET_WGS")) : 512;   // tuning switch
+    const int64_t wgs = batch * num_kv_heads > 0 ? batch * num_kv_heads : 1;
+    int64_t want = wgs >= 256 ? 1 : nvh_cdiv(target, wgs);
     const int64_t cap = max_context / 128 > 1 ? max_context / 128 : 1;
     if (want > cap) want = cap;
-    if (want > 64) want = 64;
+    if (want > 32) want = 32;
     return (int32_t)(want < 1 ? 1 : want);
 }
 
