@@ -685,26 +685,31 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_addnorm_bf16_nt_kernel(
 // rows (LDS-DMA, 128-B rows, the ring's swizzle) and the matching x fragments (global -> registers) up front, waits once,
 // multiplies, and the partial tiles meet in LDS: ((w0 + w1) + (w2 + w3)) + ((w4 + w5) + (w6 + w7)), one bf16 rounding.
 // No barrier until that sum: a wave reads only what it requested itself.
-template <int KW>
+template <int KW, int COLS = 16>
 __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, int M, int N, int K) {
     static_assert(KW == 4 || KW == 8, "four or eight waves over K");
+    // COLS = 8: half a MFMA tile of output columns per workgroup (the other eight operand rows repeat them and their
+    // results are dropped) - twice the workgroups when 16-column ones leave most CUs without one, and one CU takes in
+    // only ~35-40 GB/s from HBM
+    static_assert(COLS == 16 || COLS == 8, "16 or 8 output columns");
+    constexpr int TILE = COLS * 128;                      // bytes of one k-tile of the workgroup's weight rows
     constexpr int MAXT = 9;                               // k-tiles per wave (K <= 64 * KW * MAXT)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int TM = 1;                                 // one 16-row tile of the batch per workgroup (blockIdx.y)
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int n0 = blockIdx.x * COLS, m0 = blockIdx.y * 16;
     const int ntiles = K / BK;
     const int per = (ntiles + KW - 1) / KW;               // <= MAXT (checked on the host)
     const int t0 = wave * per, t1 = min(ntiles, t0 + per);
-    char* mine = smem + wave * (per * 2048);              // this wave's k-tiles: [tile][16 rows][128 B]
+    char* mine = smem + wave * (per * TILE);              // this wave's k-tiles: [tile][COLS rows][128 B]
 
     const int dma_r = lane >> 3, dma_pos = lane & 7;
-    const bf16* src[2];
+    const bf16* src[COLS / 8];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < COLS / 8; ++p) {
         const int r = p * 8 + dma_r;
         src[p] = w + (int64_t)min(n0 + r, N - 1) * K + (dma_pos ^ ((r >> 1) & 7)) * 8;
     }
@@ -712,8 +717,8 @@ __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     for (int i = 0; i < MAXT; ++i) {
         if (t0 + i < t1) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src[p] + (t0 + i) * BK), (LDS_AS void*)(mine + i * 2048 + p * 1024), 16, 0, 2);
+            for (int p = 0; p < COLS / 8; ++p)
+                __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src[p] + (t0 + i) * BK), (LDS_AS void*)(mine + i * TILE + p * 1024), 16, 0, 2);
         }
     }
     const int fr = lane & 15, fq = lane >> 4;
@@ -739,14 +744,15 @@ __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int kc = ks * 4 + fq;
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(mine + i * 2048 + fr * 128 + ((kc ^ ((fr >> 1) & 7)) << 4));
+                const int ar = fr & (COLS - 1);             // (COLS = 8: operand rows 8..15 repeat rows 0..7)
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(mine + i * TILE + ar * 128 + ((kc ^ ((ar >> 1) & 7)) << 4));
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, xf[j][i][ks], acc[j], 0, 0, 0);
             }
         }
     }
     // the partial tiles meet in LDS (past the k-tiles: other waves may still be reading theirs)
-    f32x4* part = reinterpret_cast<f32x4*>(smem + KW * per * 2048);          // [KW][TM][64]
+    f32x4* part = reinterpret_cast<f32x4*>(smem + KW * per * TILE);          // [KW][TM][64]
 #pragma unroll
     for (int j = 0; j < TM; ++j) part[(wave * TM + j) * 64 + lane] = acc[j];
     __syncthreads();
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(64 * KW) void gemm_kwaves_bf16_nt_kernel(
     if constexpr (KW == 8) tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     else tot = (s[0] + s[1]) + (s[2] + s[3]);
     const int n = n0 + fq * 4, m = m0 + j * 16 + fr;
-    if (n < N && m < M) {
+    if (n < N && m < M && fq * 4 < COLS) {
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(tot[e] + (bias ? bf2f(bias[n + e]) : 0.f));
@@ -958,24 +964,27 @@ static bool takes_kwaves(const GemmArgs& a) {
     return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= (getenv("NVH_NORM_GEMM_ROWS") ? 64 : 32) && a.K >= kmin && a.K <= 64 * 8 * 9 &&
            nvh_cdiv(a.N, 16) * nvh_cdiv(a.M, 16) <= 384;
 }
-template <int KW>
+template <int KW, int COLS>
 static void launch_kwaves(const GemmArgs& a) {
     constexpr int TM = 1;
-    auto kern = gemm_kwaves_bf16_nt_kernel<KW>;
+    auto kern = gemm_kwaves_bf16_nt_kernel<KW, COLS>;
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KW * 9 * 2048 + KW * TM * 1024);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, KW * 9 * COLS * 128 + KW * TM * 1024);
         configured = true;
     }
     const int per = (int)nvh_cdiv(a.K / BK, KW);
-    kern<<<dim3((unsigned)nvh_cdiv(a.N, 16), (unsigned)nvh_cdiv(a.M, 16)), 64 * KW, KW * per * 2048 + KW * TM * 1024, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M,
-                                                                                                                          a.N, a.K);
+    kern<<<dim3((unsigned)nvh_cdiv(a.N, COLS), (unsigned)nvh_cdiv(a.M, 16)), 64 * KW, KW * per * COLS * 128 + KW * TM * 1024, a.st>>>(a.x, a.xs, a.w, a.bias, a.y,
+                                                                                                                                   a.ys, a.M, a.N, a.K);
 }
 
 static int32_t dispatch_gemm(const GemmArgs& a) {
     if (takes_kwaves(a)) {
-        if (a.K / BK >= 32) launch_kwaves<8>(a);
-        else launch_kwaves<4>(a);
+        // eight output columns per workgroup while that still leaves CUs without one
+        static const bool no8 = getenv("NVH_KWAVES_NO_8") != nullptr;             // A/B switch for measurements
+        const bool narrow = !no8 && nvh_cdiv(a.N, 8) * nvh_cdiv(a.M, 16) <= 256;
+        if (a.K / BK >= 32) { if (narrow) launch_kwaves<8, 8>(a); else launch_kwaves<8, 16>(a); }
+        else { if (narrow) launch_kwaves<4, 8>(a); else launch_kwaves<4, 16>(a); }
         NVH_CHECK_LAUNCH("gemm_kwaves_bf16_nt");
         return NVH_OK;
     }

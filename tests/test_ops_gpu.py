@@ -325,7 +325,7 @@ GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024
                (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64),   # 256x256 eight-wave tile (full, ragged, one k-tile)
                (1024, 17408, 128), (512, 35000, 64),                       # ... whole rounds + a remainder launch on smaller tiles
                (1, 1024, 2048), (7, 1024, 3072), (17, 1024, 3072), (32, 1000, 2048), (3, 2048, 1536), (16, 1024, 4096),   # K split between the waves of a workgroup (decode O / down projections)
-               (8, 5120, 1600), (16, 5120, 4352), (32, 2048, 3200), (64, 1024, 3072), (47, 1024, 2048)]   # ... wider outputs, K up to 4608, up to 64 rows
+               (8, 5120, 1600), (16, 5120, 4352), (32, 2048, 3200), (64, 1024, 3072), (47, 1024, 2048), (3, 1000, 2048), (20, 520, 1536)]   # ... wider outputs, K up to 4608, up to 64 rows
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
