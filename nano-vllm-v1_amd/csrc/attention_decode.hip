@@ -358,6 +358,34 @@ __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const floa
     const int active = active_ranges(ctx_lens, bh, hq, num_splits, min_range, seq_active);
     if (active < 0) return;                                        // block-uniform
     const f32x2* ml = reinterpret_cast<const f32x2*>(ws_ml) + bh * num_splits;
+    const f32x2* acc = reinterpret_cast<const f32x2*>(ws_acc + bh * num_splits * 128) + lane;
+    float L = 0.f;
+    f32x2 A = {0.f, 0.f};
+    if (active <= 32) {                                            // block-uniform
+        // Up to 32 ranges (what the decode attention offers a short batch): this wave's accumulator records (ranges w,
+        // w + 4, ..) are requested together with the (max, sum) records instead of after the weights are known - one trip
+        // to memory less.  All eight loads are unconditional (a range past the last repeats the last: a load under a
+        // runtime condition would be waited for on its own); every range below `active` was written by this launch's
+        // attention kernel.  Same sums in the same order as the loop below.
+        f32x2 pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv[k] = acc[(int64_t)min(w + 4 * k, active - 1) * 64];
+        const f32x2 got = ml[min(lane, active - 1)];
+        const f32x2 rec0 = lane < active ? got : f32x2{-INFINITY, 0.f};
+        const float M = wave_max(rec0[1] > 0.f ? rec0[0] : -INFINITY);
+        const float mu = (M == -INFINITY) ? 0.f : M;
+        const float wgt = rec0[1] > 0.f ? __builtin_amdgcn_exp2f(rec0[0] - mu) : 0.f;
+        L += rec0[1] * wgt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = w + 4 * k;
+            const float wj = j < active ? __shfl(wgt, j & 63, 64) : 0.f;
+            if (wj != 0.f) {                                       // wave-uniform
+                A[0] += pv[k][0] * wj;
+                A[1] += pv[k][1] * wj;
+            }
+        }
+    } else {
     // every wave derives the row maximum and the weights itself (<= 256 ranges: 4 records per lane)
     f32x2 rec[4];
     float m_loc = -INFINITY;
@@ -370,9 +398,6 @@ __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const floa
     }
     const float M = wave_max(m_loc);
     const float mu = (M == -INFINITY) ? 0.f : M;
-    float L = 0.f;
-    f32x2 A = {0.f, 0.f};
-    const f32x2* acc = reinterpret_cast<const f32x2*>(ws_acc + bh * num_splits * 128) + lane;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i * 64 >= active) break;                               // block-uniform
@@ -397,6 +422,7 @@ __global__ __launch_bounds__(256) void attn_decode_combine_row_kernel(const floa
                 }
             }
         }
+    }
     }
     part[w][lane] = A;
     __syncthreads();
