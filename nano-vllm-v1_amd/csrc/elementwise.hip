@@ -105,6 +105,9 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
 
     float v[MAXC][8];
     float ss = 0.f;
+    bf16x8 wv_pre[MAXC];                                  // requested ahead of the rows: no second trip to memory after the reduction
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) wv_pre[i] = *reinterpret_cast<const bf16x8*>(w + min(lane_in_row + i * LPR, nchunk - 1) * 8);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane_in_row + i * LPR;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane_in_row + i * LPR;
         if (c < nchunk && active) {
-            bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
+            const bf16x8 wv = wv_pre[i];
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(v[i][j] * inv)) * bf2f(wv[j]));
