@@ -161,7 +161,8 @@ int32_t nvh_interleave_gate_up(const void* w, void* w_interleaved, int64_t inter
  * Qwen3DecoderLayer.forward does between two projections (models/qwen3.py:335-349: input_layernorm /
  * post_attention_layernorm with residual, layers/layernorm.py:95-141, then qkv_proj / gate_up_proj,
  * layers/linear.py:198).  s = f32(prev) + f32(residual_in) with prev [M, K] bf16, or bf16(sum of `num_slabs` fp32
- * split-K slabs [num_slabs, M, K]) when `slabs` is non-null; residual_out <- bf16(s) (must NOT alias residual_in);
+ * split-K slabs [num_slabs, M, K]) when `slabs` is non-null, or nothing at all when both are null (the first layer's
+ * input_layernorm, layers/layernorm.py:57-93: s = f32(residual_in)); residual_out <- bf16(s) (must NOT alias residual_in);
  * y[M, N] = rmsnorm(s) w[N, K]^T, or with swiglu != 0 y[M, N/2] = silu(gate) * up over a weight interleaved by
  * nvh_interleave_gate_up.  Same bits as nvh_add_rmsnorm followed by nvh_gemm_bf16_nt / nvh_gemm_swiglu_bf16_nt.
  * 1..32 rows, K a multiple of 64 up to 1024 (NVH_ENOSYS otherwise).  Every workgroup derives the rows again, so it pays only

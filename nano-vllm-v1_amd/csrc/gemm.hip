@@ -576,15 +576,30 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_addnorm_bf16_nt_kernel(
         // BM rows over PWAVES = 8 waves: a wave's rows are all requested before the first is reduced
         constexpr int RPW = (BM + PWAVES - 1) / PWAVES;
         bf16x8 pv[RPW][2], rs[RPW][2];
+        if (np.prev != nullptr) {                            // launch-uniform, outside the loops: no load under a per-element condition
 #pragma unroll
-        for (int q = 0; q < RPW; ++q) {
-            const int row = wave + q * PWAVES;
-            if (row < rows) {
+            for (int q = 0; q < RPW; ++q) {
+                const int row = wave + q * PWAVES;
+                if (row < rows) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int c = min(lane + i * 64, nchunk - 1);
-                    pv[q][i] = *reinterpret_cast<const bf16x8*>(np.prev + (int64_t)(m0 + row) * K + c * 8);
-                    rs[q][i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)(m0 + row) * K + c * 8);
+                    for (int i = 0; i < 2; ++i) {
+                        const int c = min(lane + i * 64, nchunk - 1);
+                        pv[q][i] = *reinterpret_cast<const bf16x8*>(np.prev + (int64_t)(m0 + row) * K + c * 8);
+                        rs[q][i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)(m0 + row) * K + c * 8);
+                    }
+                }
+            }
+        } else {                                             // no previous projection (the first layer): 0 + r = r exactly
+#pragma unroll
+            for (int q = 0; q < RPW; ++q) {
+                const int row = wave + q * PWAVES;
+                if (row < rows) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int c = min(lane + i * 64, nchunk - 1);
+                        pv[q][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                        rs[q][i] = *reinterpret_cast<const bf16x8*>(np.res_in + (int64_t)(m0 + row) * K + c * 8);
+                    }
                 }
             }
         }
@@ -1175,10 +1190,10 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* s
                                                 void* residual_out, const void* norm_weight, float eps, const void* w, void* y,
                                                 int64_t y_row_stride, int64_t M, int64_t N, int64_t K, int32_t swiglu,
                                                 nvh_stream_t stream) {
-    NVH_REQUIRE(residual_in && residual_out && norm_weight && w && y && (prev || slabs), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: null pointer");
+    NVH_REQUIRE(residual_in && residual_out && norm_weight && w && y, NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: null pointer");
     NVH_REQUIRE(residual_in != residual_out, NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: residual_out must not alias residual_in");
     NVH_REQUIRE(nvh_aligned16(residual_in) && nvh_aligned16(residual_out) && nvh_aligned16(norm_weight) && nvh_aligned16(w) &&
-                    (slabs ? nvh_aligned16(slabs) : nvh_aligned16(prev)) && ((uintptr_t)y & 7) == 0 && y_row_stride % 4 == 0,
+                    nvh_aligned16(slabs) && nvh_aligned16(prev) && ((uintptr_t)y & 7) == 0 && y_row_stride % 4 == 0,
                 NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: alignment");
     NVH_REQUIRE(!slabs || (num_slabs >= 1 && num_slabs <= 64), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: num_slabs %ld out of range", (long)num_slabs);
     NVH_REQUIRE(M >= 1 && M <= 64 && K >= BK && K <= 1024 && K % BK == 0 && N >= 1 && N < (1 << 30) && (swiglu ? N % 32 == 0 : N % 4 == 0),

@@ -160,14 +160,15 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     for (int l = 0; l < md->layers; ++l) {
       if (runs(2 * l + 1)) {
         // ---- input norm: layer 0 normalises the embedding; later layers add the MLP output first
-        bf16* const res = residual_after(l > 0 ? l - 1 : 0, l);     // input sites of layers 1..l-1, post sites of layers 0..l-1
+        bf16* const res = residual_after(l, l);                     // input sites of layers 0..l-1, post sites of layers 0..l-1
         bool qkv_done = false;
-        if (l == 0) {
-            FWD(nvh_rmsnorm(res, h, md->input_norm[l], w.x, h, t, h, md->eps, stream));
-        } else if (fuse_in) {
-            FWD(nvh_add_rmsnorm_gemm_bf16_nt(pending_y, pending_slabs ? w.slabs : nullptr, pending_count, res, residual_after(l, l),
-                                             md->input_norm[l], md->eps, md->qkv_w[l], w.qkv, qkv_n, t, qkv_n, h, 0, stream));
+        if (fuse_in) {
+            // (layer 0: nothing to add - the embedding rows are the residual stream)
+            FWD(nvh_add_rmsnorm_gemm_bf16_nt(l == 0 ? nullptr : pending_y, l > 0 && pending_slabs ? w.slabs : nullptr, l == 0 ? 0 : pending_count, res,
+                                             residual_after(l + 1, l), md->input_norm[l], md->eps, md->qkv_w[l], w.qkv, qkv_n, t, qkv_n, h, 0, stream));
             qkv_done = true;
+        } else if (l == 0) {
+            FWD(nvh_rmsnorm(res, h, md->input_norm[l], w.x, h, t, h, md->eps, stream));
         } else if (comm && fused_exchange) {
             FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, res, md->input_norm[l], w.x, t, h, md->eps, stream));
         } else {
@@ -227,10 +228,10 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
       }
       if (runs(2 * l + 2)) {
         // ---- add + norm
-        bf16* const res = residual_after(l, l);                     // input sites of layers 1..l, post sites of layers 0..l-1
+        bf16* const res = residual_after(l + 1, l);                 // input sites of layers 0..l, post sites of layers 0..l-1
         const bool interleaved = md->gate_up_inter && md->gate_up_inter[l];
         if (fuse_post) {
-            FWD(nvh_add_rmsnorm_gemm_bf16_nt(so > 1 ? nullptr : w.y, so > 1 ? w.slabs : nullptr, so > 1 ? so : 0, res, residual_after(l, l + 1),
+            FWD(nvh_add_rmsnorm_gemm_bf16_nt(so > 1 ? nullptr : w.y, so > 1 ? w.slabs : nullptr, so > 1 ? so : 0, res, residual_after(l + 1, l + 1),
                                              md->post_norm[l], md->eps, interleaved ? md->gate_up_inter[l] : md->gate_up_w[l],
                                              interleaved ? w.act : w.gate_up, interleaved ? md->inter : 2 * md->inter, t, 2 * md->inter, h,
                                              interleaved ? 1 : 0, stream));
@@ -263,7 +264,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
       }
     }
     if (runs(2 * md->layers + 1)) {
-        bf16* const res = residual_after(md->layers - 1, md->layers);
+        bf16* const res = residual_after(md->layers, md->layers);
         if (comm && fused_exchange) {
             FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, res, md->final_norm, hidden_out, t, h, md->eps, stream));
         } else {

@@ -305,13 +305,15 @@ int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const void* w, con
 int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* slabs, int64_t num_slabs, const void* residual_in, void* residual_out,
                                      const void* norm_weight, float eps, const void* w, void* y, int64_t y_row_stride, int64_t M, int64_t N,
                                      int64_t K, int32_t swiglu, nvh_stream_t) {
-    REQUIRE(residual_in && residual_out && norm_weight && w && y && (prev || slabs), NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: null pointer");
+    REQUIRE(residual_in && residual_out && norm_weight && w && y, NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: null pointer");
     REQUIRE(residual_in != residual_out, NVH_EINVAL, "nvh_add_rmsnorm_gemm_bf16_nt: residual_out must not alias residual_in");
     REQUIRE(M >= 1 && M <= 64 && K >= 64 && K <= 1024 && K % 64 == 0 && N >= 1 && (swiglu ? N % 32 == 0 : N % 4 == 0), NVH_ENOSYS,
             "nvh_add_rmsnorm_gemm_bf16_nt: %ld x %ld x %ld unsupported", (long)M, (long)N, (long)K);
     std::memcpy(residual_out, residual_in, (size_t)(M * K) * sizeof(bf16));
     std::vector<bf16> xn((size_t)(M * K));
-    int32_t rc = nvh_add_rmsnorm(slabs ? nullptr : prev, residual_out, norm_weight, xn.data(), M, K, eps, slabs, slabs ? num_slabs : 0, nullptr);
+    // neither a previous projection nor slabs: the plain RMSNorm of the rows (the residual stream starts with them)
+    int32_t rc = (!prev && !slabs) ? nvh_rmsnorm(residual_in, K, norm_weight, xn.data(), K, M, K, eps, nullptr)
+                                   : nvh_add_rmsnorm(slabs ? nullptr : prev, residual_out, norm_weight, xn.data(), M, K, eps, slabs, slabs ? num_slabs : 0, nullptr);
     if (rc != NVH_OK) return rc;
     if (!swiglu) return nvh_gemm_bf16_nt(xn.data(), K, w, nullptr, y, y_row_stride, M, N, K, 1, nullptr, nullptr);
     std::vector<bf16> gu((size_t)(M * N));

@@ -422,6 +422,21 @@ def test_add_rmsnorm_in_the_projection_prologue_bit_identical(ops, m, n, k, slab
     assert_gemm(yb, R.silu_mul(y_ref) if swiglu else y_ref, max_frac=0.05)
 
 
+def test_rmsnorm_without_an_add_in_the_projection_prologue(ops):
+    """The first layer's form of the fused launch: nothing to add, the rows themselves are the residual stream.  Bits of
+    nvh_rmsnorm + nvh_gemm_bf16_nt, rows copied to the second buffer."""
+    from nanovllm import _hip
+    m, n, k = 7, 4096, 1024
+    x, gamma, w = rnd(m, k, seed=71), (rnd(k, seed=72).float() * 0.1 + 1).to(BF), rnd(n, k, seed=73, scale=0.05)
+    xd, wd, gd = dev(x), dev(w), dev(gamma)
+    want = ops.linear(ops.rmsnorm(xd, gd, 1e-6), wd)
+    y, res_out = torch.empty(m, n, dtype=BF, device="cuda"), torch.empty(m, k, dtype=BF, device="cuda")
+    _hip.call("nvh_add_rmsnorm_gemm_bf16_nt", 0, 0, 0, xd.data_ptr(), res_out.data_ptr(), gd.data_ptr(), 1e-6, wd.data_ptr(), y.data_ptr(), n,
+              m, n, k, 0, torch.cuda.current_stream().cuda_stream)
+    assert_exact(y, want.cpu())
+    assert_exact(res_out, x)
+
+
 def test_add_rmsnorm_projection_argument_checks(ops):
     from nanovllm import _hip
     lib = _hip.lib()
