@@ -483,12 +483,11 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_addnorm_bf16_nt_kernel(
             for (int p = 0; p < LP; ++p)
                 __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[p] + t * BK), (LDS_AS void*)(smem + t * A_BYTES + (first + p) * 1024), 16, 0, 2);
         }
-        for (int t = 0; t < ntiles; ++t) {
-            wait_tiles_in_flight<LP, STAGES - 1>(ntiles - 1 - t);            // this loader's pieces of tile t have landed
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
+        // Every k-tile is waited for at once and ONE barrier publishes the slice: by the time the rows are normalised
+        // the slice has landed anyway, and a multiply loop without barriers lets the LDS reads of a k-step run ahead
+        // of the MFMAs of the one before.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         return;
     }
 
@@ -625,10 +624,11 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_addnorm_bf16_nt_kernel(
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // the loader waves pass it once the whole slice has landed
+    asm volatile("" ::: "memory");
+#pragma unroll 4
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // the loader wave passes it once tile t has landed
-        asm volatile("" ::: "memory");
         const char* a_base = smem + t * A_BYTES;
         const char* b_base = panel + t * (BM * 128);
 #pragma unroll
