@@ -653,7 +653,39 @@ __global__ __launch_bounds__(64 * (8 + LW)) void gemm_addnorm_bf16_nt_kernel(
         }
     }
 
-    if constexpr (SWIGLU) {
+    if constexpr (SWIGLU && TN == 1) {
+        // Two waves per 32-row block of the interleaved weight: wave 0 holds the 16 gate columns, wave 1 the matching up
+        // columns (half the chain of dependent MFMAs per wave); the up values cross to wave 0 through LDS as bf16, the
+        // rounding point of the separate kernels.  The weight slice is no longer read: its first bytes carry them.
+        static_assert(WAVES_N == 2 && WAVES_M == 1 && TM == 1, "gate wave + up wave");
+        bf16x4* cross = reinterpret_cast<bf16x4*>(smem);
+        __builtin_amdgcn_s_barrier();                              // both waves are done with the slice
+        if (wn == 1) {
+            bf16x4 u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = f2bf(acc[0][0][e]);
+            cross[lane] = u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wn == 0) {
+            const bf16x4 u = cross[lane];
+            const int n = n0;                                     // first interleaved row of the gate block
+            const int col = (n >> 5) * 16 + fq * 4;
+            const int m = m0 + fr;
+            if (n < N && m < M) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gv = bf2f(f2bf(acc[0][0][e]));
+                    const float uv = bf2f(u[e]);
+                    const float sl = gv / (1.0f + expf(-gv));
+                    o[e] = f2bf(bf2f(f2bf(sl)) * uv);
+                }
+                *reinterpret_cast<bf16x4*>(y + (int64_t)m * y_stride + col) = o;
+            }
+        }
+    } else if constexpr (SWIGLU) {
 #pragma unroll
         for (int i = 0; i + 1 < TN; i += 2) {
             const int n = n0 + wn * WN + i * 16;
@@ -1208,7 +1240,7 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* s
     // projection at 17..32 rows, the QKV projection at 33..64)
     const bool wide = nvh_cdiv(N, 32) * nvh_cdiv(M, 16) > 256;
     if (swiglu && wide) launch_gemm_addnorm<16, 64, 2, 1, 16, true, 2>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
-    else if (swiglu) launch_gemm_addnorm<16, 32, 1, 1, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
+    else if (swiglu) launch_gemm_addnorm<16, 32, 2, 1, 16, true>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     else if (wide) launch_gemm_addnorm<16, 64, 2, 1, 16, false, 2>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     else launch_gemm_addnorm<16, 32, 2, 1, 16, false>(np, (const bf16*)w, (bf16*)y, y_row_stride, (int)M, (int)N, (int)K, st);
     NVH_CHECK_LAUNCH("gemm_addnorm_bf16_nt");
