@@ -1,0 +1,6 @@
+#!/usr/bin/env bash
+# B=256 decode step and prefill chunk under environment switches given as arguments ("VAR=value" each; "-" = none), same box.
+for e in "$@" "$@"; do
+  if [ "$e" = "-" ]; then line=$(timeout -k 10 200 python bench.py --no-extras --steps 64 --warmup 8); else line=$(env $e timeout -k 10 200 python bench.py --no-extras --steps 64 --warmup 8); fi
+  echo "env=$e $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d["prefill"]["ms_per_chunk"])')"
+done
