@@ -395,7 +395,8 @@ def test_gemm_swiglu_epilogue_bit_identical_to_separate_kernels(ops, m, inter, k
                                                 (5, 1000, 512, 3, False), (16, 6144, 1024, 0, True), (17, 4096, 1024, 0, False),
                                                 (32, 2048, 1024, 2, True), (9, 96, 64, 5, False), (3, 4096, 960, 2, False),
                                                 (32, 6144, 1024, 0, True), (21, 6144, 1024, 3, True), (29, 4096, 1024, 0, False),
-                                                (64, 4096, 1024, 0, False), (45, 2048, 512, 0, True), (50, 4096, 1024, 0, False)])   # 17..32 rows: row tiles of 16; 64-column tiles with two loader waves
+                                                (64, 4096, 1024, 0, False), (45, 2048, 512, 0, True), (50, 4096, 1024, 0, False),
+                                                (20, 6176, 1024, 0, True), (2, 96, 128, 0, True), (12, 1000, 1024, 0, False)])   # ragged last tiles   # 17..32 rows: row tiles of 16; 64-column tiles with two loader waves
 def test_add_rmsnorm_in_the_projection_prologue_bit_identical(ops, m, n, k, slabs, swiglu):
     """Residual add + RMSNorm + projection in one launch (decode batches) against the two launches: the projection
     output and the new residual carry the same bits, from a bf16 input or from split-K slabs of the previous projection,
