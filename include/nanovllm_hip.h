@@ -165,8 +165,10 @@ int32_t nvh_interleave_gate_up(const void* w, void* w_interleaved, int64_t inter
  * input_layernorm, layers/layernorm.py:57-93: s = f32(residual_in)); residual_out <- bf16(s) (must NOT alias residual_in);
  * y[M, N] = rmsnorm(s) w[N, K]^T, or with swiglu != 0 y[M, N/2] = silu(gate) * up over a weight interleaved by
  * nvh_interleave_gate_up.  Same bits as nvh_add_rmsnorm followed by nvh_gemm_bf16_nt / nvh_gemm_swiglu_bf16_nt.
- * 1..32 rows, K a multiple of 64 up to 1024 (NVH_ENOSYS otherwise).  Every workgroup derives the rows again, so it pays only
- * while that is a few KB: nvh_add_rmsnorm_gemm_fused says whether a caller should take it. */
+ * 1..64 rows, K a multiple of 64 up to 1024 (NVH_ENOSYS otherwise).  Every workgroup derives the rows again, so it pays only
+ * while that is a few KB: nvh_add_rmsnorm_gemm_fused says whether a caller should take it - 0: no; 1: yes; 2 (33..64 rows): only
+ * where every step of that size takes it (nvh_qwen3_forward does for pure decode steps), because a row count that changes route
+ * changes the order of a few fp32 sums. */
 int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* slabs, int64_t num_slabs, const void* residual_in,
                                      void* residual_out, const void* norm_weight, float eps, const void* w, void* y,
                                      int64_t y_row_stride, int64_t M, int64_t N, int64_t K, int32_t swiglu,

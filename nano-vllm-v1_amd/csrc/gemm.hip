@@ -1008,7 +1008,7 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
 static bool takes_kwaves(const GemmArgs& a) {
     static const bool off = getenv("NVH_NO_KWAVES") != nullptr;                   // A/B switch for measurements
     static const int kmin = getenv("NVH_KWAVES_KMIN") ? atoi(getenv("NVH_KWAVES_KMIN")) : 1536;   // tuning switch
-    return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= (getenv("NVH_NORM_GEMM_ROWS") ? 64 : 32) && a.K >= kmin && a.K <= 64 * 8 * 9 &&
+    return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= 64 && a.K >= kmin && a.K <= 64 * 8 * 9 &&
            nvh_cdiv(a.N, 16) * nvh_cdiv(a.M, 16) <= 384;
 }
 template <int KW, int COLS>
@@ -1204,18 +1204,18 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_fused(int64_t M, int64_t N, int64_t K, i
     const bool off = getenv("NVH_NO_NORM_GEMM") != nullptr;                        // A/B switch for measurements and tests (read per call)
     // KB a workgroup reads to derive the rows again (every workgroup of the grid does): beyond this the norm launch is cheaper
     static const int64_t budget_kb = getenv("NVH_NORM_GEMM_KB") ? atoll(getenv("NVH_NORM_GEMM_KB")) : 128;
-    // Rows a caller is advised to bring.  The kernels take up to 64 (33..64 rows measured 2.6-3.7 % faster per decode step:
-    // 2.12 / 2.22 / 2.39 ms against 2.17 / 2.29 / 2.48 ms at 40 / 48 / 64 sequences), the default stays at 32: every
-    // row count that changes route changes the order of a few fp32 sums, and serving steps of 33..64 tokens are mostly
-    // mixed ones whose neighbours take the generic route.
-    static const int64_t max_rows = getenv("NVH_NORM_GEMM_ROWS") ? atoll(getenv("NVH_NORM_GEMM_ROWS")) : 32;
+    // 1: take it.  2 (33..64 rows; measured 2.6-3.7 % per decode step at 40..64 sequences): take it only where every step
+    // of that size does - every row count that changes route changes the order of a few fp32 sums, and steps of 33..64
+    // tokens are mostly mixed ones whose neighbours take the generic route; the step executor takes it for pure decode steps.
+    static const int64_t max_rows = getenv("NVH_NORM_GEMM_ROWS") ? atoll(getenv("NVH_NORM_GEMM_ROWS")) : 64;   // tuning switch
     if (off || M < 1 || M > 64 || M > max_rows || K < BK || K > 1024 || K % BK != 0 || N < 1 || N >= (1 << 30) || num_slabs < 0 || num_slabs > 64) return 0;
     if (swiglu ? N % 32 != 0 : N % 4 != 0) return 0;
     // one workgroup per CU (its LDS holds the whole weight slice): beyond 32 rows only grids of one round
     if (M > 32 && nvh_cdiv(N, 64) * nvh_cdiv(M, 16) > 256) return 0;
     const int64_t rows = M < 16 ? M : 16;                                          // per workgroup
     const int64_t kb = rows * (num_slabs > 0 ? num_slabs * 4 * K : 2 * K) / 1024;
-    return kb <= budget_kb;
+    if (kb > budget_kb) return 0;
+    return M <= 32 ? 1 : 2;
 }
 
 extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* slabs, int64_t num_slabs, const void* residual_in,

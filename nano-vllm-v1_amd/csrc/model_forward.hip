@@ -121,7 +121,13 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     // decode batches whose add + norm happens in the next projection's prologue: no slabs either (every workgroup of
     // that projection would sum them again); the O / down projections then split K between the waves of a workgroup
     const bool no_full_k = getenv("NVH_DECODE_SLABS") != nullptr;                 // A/B switch for measurements and tests (read per call)
-    const bool full_k = !no_full_k && t <= 64 && !md->comm && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, 0, 0);
+    // (an answer of 2 - 33..64 rows - only for pure decode steps: every decode step of that size then takes the same route)
+    const int32_t fused_limit = st->mode == NVH_MODE_DECODE ? 2 : 1;
+    auto fused_ok = [&](int64_t n, int64_t slabs, int32_t swiglu) {
+        const int32_t r = nvh_add_rmsnorm_gemm_fused(t, n, h, slabs, swiglu);
+        return r >= 1 && r <= fused_limit;
+    };
+    const bool full_k = !no_full_k && t <= 64 && !md->comm && fused_ok(qkv_n, 0, 0);
     const int32_t so = sharded || full_k ? 1 : split_for(t, h, qsz), sd = sharded || full_k ? 1 : split_for(t, h, md->inter);
     auto runs = [&](int part) { return part >= first_part && part <= last_part; };
     const int32_t sq = split_for_qkv(t, qkv_n, h);
@@ -150,9 +156,8 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     // buffer and writes it to the other, so the residual stream alternates between w.residual and w.residual2; which
     // one holds it follows from the number of fused sites passed (the same for every layer, so a step cut into
     // parts agrees with itself).
-    const bool fuse_in = !comm && t <= 64 && sq == 1 && nvh_add_rmsnorm_gemm_fused(t, qkv_n, h, pending_count, 0);
-    const bool fuse_post = !comm && t <= 64 && nvh_add_rmsnorm_gemm_fused(t, 2 * md->inter, h, so > 1 ? so : 0, 1) &&
-                           nvh_add_rmsnorm_gemm_fused(t, 2 * md->inter, h, so > 1 ? so : 0, 0);
+    const bool fuse_in = !comm && t <= 64 && sq == 1 && fused_ok(qkv_n, pending_count, 0);
+    const bool fuse_post = !comm && t <= 64 && fused_ok(2 * md->inter, so > 1 ? so : 0, 1) && fused_ok(2 * md->inter, so > 1 ? so : 0, 0);
     auto residual_after = [&](int in_sites, int post_sites) {
         const int swaps = (fuse_in ? in_sites : 0) + (fuse_post ? post_sites : 0);
         return (swaps & 1) ? w.residual2 : w.residual;

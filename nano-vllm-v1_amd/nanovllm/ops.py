@@ -223,7 +223,7 @@ def linear_swiglu(x: torch.Tensor, weight_interleaved: torch.Tensor) -> torch.Te
 def add_rmsnorm_linear(x: torch.Tensor | None, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float, weight: torch.Tensor,
                        partials: torch.Tensor | None = None, swiglu: bool = False) -> tuple[torch.Tensor, torch.Tensor]:
     """(y, new_residual) of add_rmsnorm followed by linear (or linear_swiglu over an interleaved weight) in ONE launch:
-    decode batches of 1..32 rows with rows of at most 1024 elements.  ``residual`` is NOT modified; bit-identical to the
+    decode batches of 1..64 rows with rows of at most 1024 elements.  ``residual`` is NOT modified; bit-identical to the
     two calls.  ``fused_add_rmsnorm_linear`` tells whether the step executor would take it."""
     _gpu_bf16(residual, norm_weight, weight)
     k = residual.shape[-1]
@@ -245,7 +245,7 @@ def add_rmsnorm_linear(x: torch.Tensor | None, residual: torch.Tensor, norm_weig
 
 
 def fused_add_rmsnorm_linear(m: int, n: int, k: int, num_partials: int = 0, swiglu: bool = False) -> bool:
-    return bool(_hip.lib().nvh_add_rmsnorm_gemm_fused(m, n, k, num_partials, 1 if swiglu else 0))
+    return _hip.lib().nvh_add_rmsnorm_gemm_fused(m, n, k, num_partials, 1 if swiglu else 0) == 1
 
 
 def splitk_reduce(partials: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
