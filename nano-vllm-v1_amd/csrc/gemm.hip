@@ -280,18 +280,19 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         // The tile (one head of BM tokens) goes through LDS as bf16 - the rounding point of the separate GEMM - and
         // is then walked like the stand-alone q/k epilogue kernel: 16 lanes per row, 8 columns per lane, the same
         // device function, so both routes give the same bits.
-        static_assert(BN == 128 && NW == 4 && !SWIGLU, "one head per tile, 256 threads");
+        static_assert(BN == 128 && (NW == 4 || NW == 8) && !SWIGLU, "one head per tile, 256 or 512 threads");
+        constexpr int RPP = NW * 4;                              // rows of the tile per pass: 16 lanes per row
         constexpr int TS = 136;                                  // LDS row stride in elements (272 B: rows land in different banks)
         const int c = tid & 15, rr = tid >> 4;
         const int head = n0 >> 7;                                // block-uniform
         const bool normed = head < qe.hq + qe.hkv;
         // cos / sin rows of this thread's 8 tokens: requested before the tile goes through LDS, so their latency
         // (position, then table row) hides behind the staging
-        f32x4 cs[BM / 16][4];
+        f32x4 cs[BM / RPP][4];
         if (normed) {
 #pragma unroll
-            for (int p = 0; p < BM / 16; ++p) {
-                const float* cs_row = qe.cos_sin + qe.positions[min(m0 + p * 16 + rr, M - 1)] * 128 + 8 * (c & 7);
+            for (int p = 0; p < BM / RPP; ++p) {
+                const float* cs_row = qe.cos_sin + qe.positions[min(m0 + p * RPP + rr, M - 1)] * 128 + 8 * (c & 7);
                 cs[p][0] = *reinterpret_cast<const f32x4*>(cs_row);
                 cs[p][1] = *reinterpret_cast<const f32x4*>(cs_row + 4);
                 cs[p][2] = *reinterpret_cast<const f32x4*>(cs_row + 64);
@@ -315,17 +316,17 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         bf16* cache = head < qe.hq ? nullptr : (normed ? qe.k_cache : qe.v_cache);
         const int kvh = head - qe.hq - (normed ? 0 : qe.hkv);
         // all epilogue arithmetic first, the stores afterwards
-        bf16x8 outv[BM / 16];
+        bf16x8 outv[BM / RPP];
 #pragma unroll
-        for (int p = 0; p < BM / 16; ++p) {
-            const int row = p * 16 + rr, m = min(m0 + row, M - 1);          // rows past M compute on row M-1, store nothing
+        for (int p = 0; p < BM / RPP; ++p) {
+            const int row = p * RPP + rr, m = min(m0 + row, M - 1);          // rows past M compute on row M-1, store nothing
             bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TS + c * 8);
             if (m >= qe.raw_rows && normed) v = qknorm_rope_head_cs(v, wv, cs[p][0], cs[p][1], cs[p][2], cs[p][3], c, qe.eps);   // uniform over a 16-lane row
             outv[p] = v;
         }
 #pragma unroll
-        for (int p = 0; p < BM / 16; ++p) {
-            const int m = m0 + p * 16 + rr;
+        for (int p = 0; p < BM / RPP; ++p) {
+            const int m = m0 + p * RPP + rr;
             if (m >= M) continue;
             *reinterpret_cast<bf16x8*>(y + (int64_t)m * y_stride + n0 + c * 8) = outv[p];
             if (m >= qe.raw_rows && cache != nullptr && qe.slot_mapping != nullptr) {
@@ -857,7 +858,7 @@ template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
 void launch_gemm(const GemmArgs& a) {
     static const bool no_nt = getenv("NVH_GEMM_NO_NT") != nullptr;   // A/B switch for tuning
     const bool nt = a.M <= BM && !no_nt;
-    if constexpr (BM == 128 && BN == 128 && WAVES_N == 2 && WAVES_M == 2) {
+    if constexpr (BM == 128 && BN == 128 && WAVES_N == 2 && (WAVES_M == 2 || WAVES_M == 4)) {
         if (a.qkv) {
             if (nt) launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, true, false, true>(a);
             else launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, false, true>(a);
@@ -1089,12 +1090,15 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;
         case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
-        case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;
+        case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;      // (eight waves on a grid of exactly 256: a 1024-token chunk 2.83 -> 2.94 ms)
         case T128x64: launch_gemm<128, 64, 2, 2, 4>(a); break;
         case T128x128:
             // up to one workgroup per CU: nothing shares the CU's LDS, so a third stage (96 KB) keeps two tiles in
             // flight instead of one (1024 x 4096 x 1024: 19.1 -> 17.2 us); larger grids want two residents of 64 KB
-            if (nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k <= 256) launch_gemm<128, 128, 2, 2, 3>(a);
+            // the QKV projection with its epilogue on a grid of exactly one workgroup per CU: eight waves (two per SIMD, one
+            // barrier apart; the epilogue walks 32 rows per pass) - a 1024-token chunk 2.90 -> 2.82 ms
+            if (!a.swiglu && getenv("NVH_QKV_NO_8WAVE") == nullptr && nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k == 256) launch_gemm<128, 128, 2, 4, 3>(a);
+            else if (nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k <= 256) launch_gemm<128, 128, 2, 2, 3>(a);
             else launch_gemm<128, 128, 2, 2, 2>(a);
             break;
         case T256x128: launch_gemm<256, 128, 2, 2, 3>(a); break;
