@@ -1095,9 +1095,11 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T128x128:
             // up to one workgroup per CU: nothing shares the CU's LDS, so a third stage (96 KB) keeps two tiles in
             // flight instead of one (1024 x 4096 x 1024: 19.1 -> 17.2 us); larger grids want two residents of 64 KB
-            // the QKV projection with its epilogue on a grid of exactly one workgroup per CU: eight waves (two per SIMD, one
-            // barrier apart; the epilogue walks 32 rows per pass) - a 1024-token chunk 2.90 -> 2.82 ms
-            if (!a.swiglu && getenv("NVH_QKV_NO_8WAVE") == nullptr && nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k == 256) launch_gemm<128, 128, 2, 4, 3>(a);
+            // a nearly full round of one workgroup per CU over a short K (the QKV projection of a prefill chunk, epilogue
+            // included): eight waves (two per SIMD, one barrier apart; the QKV epilogue walks 32 rows per pass).  1024 / 896 x
+            // 4096 x 1024: 16.1 / 15.1 -> 14.9 / 14.4 us, a 1024-token chunk 2.89 -> 2.81 ms; K = 2048: 25.5 -> 26.2 us (not taken)
+            const int64_t tiles128 = nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k;
+            if (!a.swiglu && getenv("NVH_QKV_NO_8WAVE") == nullptr && tiles128 >= 200 && tiles128 <= 256 && a.K / a.split_k <= 1536) launch_gemm<128, 128, 2, 4, 3>(a);
             else if (nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k <= 256) launch_gemm<128, 128, 2, 2, 3>(a);
             else launch_gemm<128, 128, 2, 2, 2>(a);
             break;
