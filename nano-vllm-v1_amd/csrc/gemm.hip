@@ -1092,7 +1092,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
         case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;      // (eight waves on a grid of exactly 256: a 1024-token chunk 2.83 -> 2.94 ms)
         case T128x64: launch_gemm<128, 64, 2, 2, 4>(a); break;
-        case T128x128:
+        case T128x128: {
             // up to one workgroup per CU: nothing shares the CU's LDS, so a third stage (96 KB) keeps two tiles in
             // flight instead of one (1024 x 4096 x 1024: 19.1 -> 17.2 us); larger grids want two residents of 64 KB
             // a nearly full round of one workgroup per CU over a short K (the QKV projection of a prefill chunk, epilogue
@@ -1103,6 +1103,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
             else if (nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k <= 256) launch_gemm<128, 128, 2, 2, 3>(a);
             else launch_gemm<128, 128, 2, 2, 2>(a);
             break;
+        }
         case T256x128: launch_gemm<256, 128, 2, 2, 3>(a); break;
         case T256x256: launch_gemm<256, 256, 2, 4, 2>(a); break;
     }
