@@ -90,20 +90,23 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
     // Workgroups go to the 8 XCDs round-robin by linear id.  With xcd_strip = 8 or 4 (host: gridDim.x a multiple of it,
-    // gridDim.z == 1) XCD i takes the i-th eighth of the tiles in an order that walks strips of that many column tiles row
+    // any gridDim.z) XCD i takes the i-th eighth of the tiles in an order that walks strips of that many column tiles row
     // by row, so the workgroups resident on an XCD at one time share a few column tiles of W and a few row tiles of x in
     // its L2 (Qwen3-14B shapes, 1024 rows: a prefill chunk 27.8 -> 27.15 ms; K = 1024: no change).
-    int bx = blockIdx.x, by = blockIdx.y;
+    // K-slabs (gridDim.z) count as further tile rows: slab z of row tile y is row y + gridDim.y * z.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (xcd_strip) {
-        const int id = blockIdx.x + gridDim.x * blockIdx.y, total = gridDim.x * gridDim.y;
+        const int rows = gridDim.y * gridDim.z;
+        const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total = gridDim.x * rows;
         const int xcd = id & 7, nl = xcd * (total >> 3) + min(xcd, total & 7) + (id >> 3);
-        const int sh = xcd_strip == 8 ? 3 : 2, per_strip = (int)gridDim.y << sh;
-        const int strip = nl / per_strip, in = nl - strip * per_strip;
+        const int sh = xcd_strip == 8 ? 3 : 2, per_strip = rows << sh;
+        const int strip = nl / per_strip, in = nl - strip * per_strip, row = in >> sh;
         bx = (strip << sh) + (in & (xcd_strip - 1));
-        by = in >> sh;
+        bz = row / (int)gridDim.y;
+        by = row - bz * (int)gridDim.y;
     }
     const int n0 = bx * BN, m0 = by * BM;
-    const int kbeg = blockIdx.z * k_per_split;
+    const int kbeg = bz * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
     const int ntiles = max(0, (kend - kbeg) / BK);
 
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
             const int m = m0 + wm * WM + j * 16 + fr;
             if (m >= M) continue;
             if (partials != nullptr) {
-                *reinterpret_cast<f32x4*>(partials + ((int64_t)blockIdx.z * M + m) * N + n) = acc[i][j];
+                *reinterpret_cast<f32x4*>(partials + ((int64_t)bz * M + m) * N + n) = acc[i][j];
             } else {
                 bf16x4 o;
 #pragma unroll
@@ -865,7 +868,7 @@ void launch_gemm_nt(const GemmArgs& a) {
     dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
     static const bool no_xcd = getenv("NVH_GEMM_NO_XCD") != nullptr;            // A/B switch for measurements
     // prefill-sized products only: at 256 rows (a decode batch, 64-row tiles) the same order made a step 0.7 % slower
-    const int xcd_strip = (no_xcd || grid.z != 1 || grid.y == 1 || a.M < 512) ? 0 : grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 0;
+    const int xcd_strip = (no_xcd || grid.y * grid.z == 1 || a.M < 512) ? 0 : grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 0;
     kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split,
                                                        a.qkv ? *a.qkv : QkvEpilogue{}, wide, a.sample ? *a.sample : SampleEpilogue{}, xcd_strip);
 }
