@@ -78,7 +78,7 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
     const bf16* __restrict__ q, int64_t q_stride, const bf16* __restrict__ kp, const bf16* __restrict__ vp,
     int64_t kv_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ tables, int64_t table_stride, int hkv, float scale_log2, bf16* __restrict__ out,
-    int num_splits, int tiles_per_split, float* __restrict__ ws_acc, float* __restrict__ ws_ml) {
+    int num_splits, int tiles_per_split, float* __restrict__ ws_acc, float* __restrict__ ws_ml, int head_major) {
     constexpr int NW1 = G * RB, NW = NW1 * KS, BQ = 32 * RB;     // NW1: waves of one key group
     constexpr int PIECES = 32 * KS;                              // 1-KiB DMA pieces per step: KS x (K + V tile), 4 keys each
     constexpr int PW = (PIECES + NW - 1) / NW;                   // pieces per wave (uniform; extras duplicate)
@@ -89,10 +89,13 @@ __global__ __launch_bounds__(G * RB * KS * 64, (G * RB * KS <= 4 && STAGES * KS 
     static_assert(KS == 1 || 32 % NW == 0, "with key groups a wave's piece i must belong to the same tile for every wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES x KS x (K tile + V tile)
 
-    const int b = blockIdx.z / num_splits, split = blockIdx.z % num_splits, kvh = blockIdx.y;
+    // head_major: the kv head is the fastest grid dimension, so with 8 (4, 2) kv heads the workgroups of one head all land
+    // on the same XCD (pair, four) and its L2 fetches that head's K/V once for all of its query blocks
+    const int b = blockIdx.z / num_splits, split = blockIdx.z % num_splits, kvh = head_major ? blockIdx.x : blockIdx.y;
+    const int qblock = head_major ? blockIdx.y : blockIdx.x, qblocks = head_major ? gridDim.y : gridDim.x;
     const int q_beg = cu_q[b], lq = cu_q[b + 1] - q_beg;
     const int k_beg = cu_k[b], lk = cu_k[b + 1] - k_beg;
-    const int qb0 = (gridDim.x - 1 - blockIdx.x) * BQ;           // last (longest, under the causal mask) query blocks first
+    const int qb0 = (qblocks - 1 - qblock) * BQ;           // last (longest, under the causal mask) query blocks first
     if (qb0 >= lq) return;
     const int hq = hkv * G;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -538,6 +541,7 @@ struct VarlenArgs {
     bf16* out;
     int num_splits, tiles_per_split;
     float *ws_acc, *ws_ml;
+    int head_major;
 };
 
 template <int G, int RB, int KS, int STAGES>
@@ -551,10 +555,10 @@ void launch_varlen(bool paged, dim3 grid, hipStream_t st, const VarlenArgs& a) {
     }
     if (paged)
         attn_varlen_kernel<G, RB, KS, STAGES, true><<<grid, G * RB * KS * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
-                                                                                         a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
+                                                                                         a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml, a.head_major);
     else
         attn_varlen_kernel<G, RB, KS, STAGES, false><<<grid, G * RB * KS * 64, smem, st>>>(a.q, a.qs, a.k, a.v, a.kvs, a.cu_q, a.cu_k, a.tables, a.ts,
-                                                                                          a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml);
+                                                                                          a.hkv, a.sl2, a.out, a.num_splits, a.tiles_per_split, a.ws_acc, a.ws_ml, a.head_major);
 }
 
 // Query rows per workgroup: 4-5 waves per key group (8 for G = 8), each 32 rows of one query head.
@@ -626,10 +630,17 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
     // whole steps of `ks` tiles per key range (a step's tiles then share one page of the block table)
     VarlenArgs a{(const bf16*)q, (const bf16*)k, (const bf16*)v, q_token_stride, kv_token_stride, cu_seqlens_q, cu_seqlens_k,
                  block_tables, table_stride, (int)num_kv_heads, softmax_scale * LOG2E, (bf16*)out, num_splits,
-                 (int)(nvh_cdiv(nvh_cdiv(tiles, num_splits), ks) * ks), ws_acc, ws_ml};
+                 (int)(nvh_cdiv(nvh_cdiv(tiles, num_splits), ks) * ks), ws_acc, ws_ml, 0};
+    // Grid order (us per launch, 16 q / 8 kv heads, 1024 query rows, query-block-major vs head-major): uncut 1024 keys 22.5 vs
+    // 22.1, 8192 keys 128.1 vs 127.6; 2 x 512 x 512: 15.3 vs 13.4; 8 x 128 x 128: 9.35 vs 8.97; in two key ranges 2048 keys
+    // 35.3 vs 38.2, 4096 keys 52.6 vs 53.8, 8192 keys 93.3 vs 87.8 (four ranges 91.1 vs 85.0): head-major unless a cut
+    // launch has fewer than 6144 keys (NVH_ATTN_HEAD_MAJOR=0 / 1 forces one order for measurements).
+    static const int force_hm = getenv("NVH_ATTN_HEAD_MAJOR") ? atoi(getenv("NVH_ATTN_HEAD_MAJOR")) : -1;
+    a.head_major = force_hm >= 0 ? force_hm : (num_splits == 1 || max_seqlen_k >= 6144);
 #define LAUNCH_VL(GG, RBB, KSS, STG)                                                                                        \
     do {                                                                                                                    \
         dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));      \
+        if (a.head_major) grid = dim3(grid.y, grid.x, grid.z);                                                              \
         launch_varlen<GG, RBB, KSS, STG>(paged, grid, st, a);                                                               \
     } while (0)
     switch (g) {
