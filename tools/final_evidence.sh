@@ -1,0 +1,33 @@
+#!/usr/bin/env bash
+# Bench line, profiles (tools/collect_evidence.sh), the Qwen3-14B prefill chunk by kernel and the var-len attention
+# sweep in both grid orders, for the build in the tree; everything under gpurun_out/ev/.  Each GPU step runs under its own
+# time limit; the script stops at the first failure.
+set -euo pipefail
+R="${GRAFT_REPO_ROOT:-/root/repo}"
+O="$R/gpurun_out/ev"
+mkdir -p "$O"
+cd "$R"
+timeout -k 10 500 python3 -u bench.py > "$O/bench.json" 2> "$O/bench.err"
+bash tools/collect_evidence.sh > "$O/collect.log" 2>&1
+cd /tmp
+export TMPDIR=/tmp
+NANOVLLM_PROBE_MODEL=qwen3-14b timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$O/pf14" -o p -- python3 "$R/tools/prefill_probe.py" 1024 0 4 > "$O/prefill_probe_14b.log" 2>&1
+python3 "$R/tools/trace_breakdown.py" "$(find "$O/pf14" -name '*kernel_trace.csv' | head -1)" > "$O/prefill_chunk_1024_14b.csv"
+rm -rf "$O/pf14"
+cd "$R"
+{
+    echo "# NVH_ATTN_HEAD_MAJOR=0 (query-block-major)"
+    NVH_ATTN_HEAD_MAJOR=0 timeout -k 10 200 python3 -u tools/attn_varlen_sweep.py 2> /dev/null
+    echo "# NVH_ATTN_HEAD_MAJOR=1 (kv-head-major)"
+    NVH_ATTN_HEAD_MAJOR=1 timeout -k 10 200 python3 -u tools/attn_varlen_sweep.py 2> /dev/null
+    echo "# default rule"
+    timeout -k 10 200 python3 -u tools/attn_varlen_sweep.py 2> /dev/null
+} > "$O/attn_varlen_grid_order.txt"
+{
+    NANOVLLM_PROBE_MODEL=qwen3-14b timeout -k 10 200 python3 -u tools/prefill_probe.py 1024 0 5 2> /dev/null | tail -1
+    echo "# NVH_GEMM_NO_XCD=1"
+    NVH_GEMM_NO_XCD=1 NANOVLLM_PROBE_MODEL=qwen3-14b timeout -k 10 200 python3 -u tools/prefill_probe.py 1024 0 5 2> /dev/null | tail -1
+} > "$O/prefill_14b_xcd_order.txt"
+timeout -k 10 200 python3 -u tools/prefill_two_streams_probe.py 1024 8 2 2> /dev/null | tail -1 > "$O/prefill_two_streams.txt"
+timeout -k 10 200 python3 -u tools/prefill_two_streams_probe.py 1024 8 4 2> /dev/null | tail -1 >> "$O/prefill_two_streams.txt"
+ls "$O"
