@@ -1124,6 +1124,11 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
             // rounds of 256 CUs): 128 x 96 tiles make whole rounds (512).  Taken when rounds x tile area, the narrower tile
             // priced 5 % dearer per column, comes out lower: a 1024-token chunk 2.80 -> 2.77 ms.  (128 x 64 tiles, 768 = three
             // whole rounds: 2.81; a third stage on the 96-wide tile, one resident per CU: 2.95.)
+            // ... and a nearly full single round of eight-wave 128 x 192 tiles (1024 x 6144: exactly 256) ahead of both, over a
+            // short K like the QKV case above: a 1024-token chunk 2.789 -> 2.771 ms
+            else if (a.swiglu && a.N % 192 == 0 && getenv("NVH_SWIGLU_NO_192") == nullptr && a.K <= 1536 && a.split_k == 1 &&
+                     nvh_cdiv(a.M, 128) * (a.N / 192) >= 200 && nvh_cdiv(a.M, 128) * (a.N / 192) <= 256)
+                launch_gemm<128, 192, 2, 4, 3>(a);
             else if (a.swiglu && a.N % 96 == 0 && getenv("NVH_SWIGLU_NO_96") == nullptr &&
                      nvh_cdiv(nvh_cdiv(a.M, 128) * (a.N / 96) * a.split_k, 256) * 96 * 105 < nvh_cdiv(tiles128, 256) * 128 * 100)
                 launch_gemm<128, 96, 1, 4, 2>(a);

@@ -325,7 +325,8 @@ GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024
                (1024, 16384, 256), (1000, 15400, 192), (2048, 8192, 64),   # 256x256 eight-wave tile (full, ragged, one k-tile)
                (1024, 17408, 128), (512, 35000, 64),                       # ... whole rounds + a remainder launch on smaller tiles
                (1, 1024, 2048), (7, 1024, 3072), (17, 1024, 3072), (32, 1000, 2048), (3, 2048, 1536), (16, 1024, 4096),   # K split between the waves of a workgroup (decode O / down projections)
-               (8, 5120, 1600), (16, 5120, 4352), (32, 2048, 3200), (64, 1024, 3072), (47, 1024, 2048), (3, 1000, 2048), (20, 520, 1536)]   # ... wider outputs, K up to 4608, up to 64 rows
+               (8, 5120, 1600), (16, 5120, 4352), (32, 2048, 3200), (64, 1024, 3072), (47, 1024, 2048), (3, 1000, 2048), (20, 520, 1536),   # ... wider outputs, K up to 4608, up to 64 rows
+               (520, 1536, 128), (576, 768, 64), (600, 768, 128), (1100, 1280, 192)]   # XCD-aware tile order: strips of 8 / 4 column tiles, odd and ragged row-tile counts, a tile count that 8 does not divide
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
@@ -672,6 +673,20 @@ def test_attn_varlen_paged_vs_oracle(ops, hq, hkv, case):
     ref = R.attention_varlen(q, None, None, cu_q, cu_k, scale, kc, vc, bt)
     # key-range splits: heuristic (0), none (1), and counts that leave some ranges empty for short sequences
     for splits in (0, 1, 3, 8):
+        got = ops.attn_varlen(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(lens_q), scale, dev(bt),
+                              max_seqlen_k=max(lens_k), num_splits=splits)
+        assert_close(got, ref, 1.5e-2, 2e-2)
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (10, 2)])
+def test_attn_varlen_long_cut_launch_vs_oracle(ops, hq, hkv):
+    """Key ranges over 6144+ keys: such a launch walks its grid kv-head-major like an uncut one (shorter cut launches
+    walk it query-block-major); both orders must cover every (query block, head, range) once."""
+    lens_q, lens_k = [130, 40], [6500, 6210]
+    q, kc, vc, bt, cu_q, cu_k = _paged_case(77, lens_q, lens_k, hq, hkv, num_pages=56)
+    scale = 128 ** -0.5
+    ref = R.attention_varlen(q, None, None, cu_q, cu_k, scale, kc, vc, bt)
+    for splits in (2, 5):
         got = ops.attn_varlen(dev(q), dev(kc), dev(vc), dev(cu_q), dev(cu_k), max(lens_q), scale, dev(bt),
                               max_seqlen_k=max(lens_k), num_splits=splits)
         assert_close(got, ref, 1.5e-2, 2e-2)
