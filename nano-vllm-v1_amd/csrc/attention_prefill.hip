@@ -637,6 +637,7 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
     // launch has fewer than 6144 keys (NVH_ATTN_HEAD_MAJOR=0 / 1 forces one order for measurements).
     static const int force_hm = getenv("NVH_ATTN_HEAD_MAJOR") ? atoi(getenv("NVH_ATTN_HEAD_MAJOR")) : -1;
     a.head_major = force_hm >= 0 ? force_hm : (num_splits == 1 || max_seqlen_k >= 6144);
+    if (nvh_cdiv(max_seqlen_q, 32) > 65535) a.head_major = 0;          // the query blocks would not fit gridDim.y
 #define LAUNCH_VL(GG, RBB, KSS, STG)                                                                                        \
     do {                                                                                                                    \
         dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));      \
