@@ -482,10 +482,13 @@ extern "C" int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_
     // the workgroup count aimed for, 256 / 512 / 1024 / 2048): 1 sequence 0.90 / 0.92 (64 ranges offered; 0.90 with 32)
     // / - / -, 8 sequences 1.13 / 1.15 / 1.17 / 1.31, 16 sequences 1.43 / 1.39 / 1.50 / 1.60, 32 sequences 1.70 (one
     // range, no merge launch) / 1.73 / 1.81 / 1.93: every range costs a workgroup's prologue and a record for the merge,
-    // every range less a longer chain of dependent trips.
+    // every range less a longer chain of dependent trips.  Ranges for batches that already give every CU a workgroup
+    // (tools/decode_splits_ab.sh; one range / 1024 / 2048 workgroups aimed for): 32 sequences 1.67 / 1.77 / 1.89 ms, 64
+    // sequences 2.39 / 2.60 / 2.67, 128 sequences 3.95 / 3.95 / 4.22.
     static const int64_t target = getenv("NVH_DECODE_TARGET_WGS") ? atoll(getenv("NVH_DECODE_TARGET_WGS")) : 512;   // tuning switch
     const int64_t wgs = batch * num_kv_heads > 0 ? batch * num_kv_heads : 1;
-    int64_t want = wgs >= 256 ? 1 : nvh_cdiv(target, wgs);
+    static const int64_t full = getenv("NVH_DECODE_FULL_WGS") ? atoll(getenv("NVH_DECODE_FULL_WGS")) : 256;        // tuning switch
+    int64_t want = wgs >= full ? 1 : nvh_cdiv(target, wgs);
     const int64_t cap = max_context / 128 > 1 ? max_context / 128 : 1;
     if (want > cap) want = cap;
     if (want > 32) want = 32;
