@@ -592,6 +592,10 @@ extern "C" int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch
         cap = tiles / 4;
     } else {
         s = (256 + blocks / 2) / (blocks > 0 ? blocks : 1);     // nearest count to one workgroup per CU
+        // from 6144 keys (where the launch walks its grid kv-head-major) four ranges: 8192 keys 85-88 us against 88-93 us in
+        // two; the chunks 6-8 of an 8192-token prompt 4.02 / 4.26 / 4.57 -> 3.96 / 4.18 / 4.47 ms
+        static const int64_t long_s = getenv("NVH_VARLEN_LONG_SPLITS") ? atoll(getenv("NVH_VARLEN_LONG_SPLITS")) : 4;   // tuning switch
+        if (max_seqlen_k >= 6144 && s < long_s) s = long_s;
         cap = tiles / 16;                                      // at least 1024 keys per range
     }
     if (s > cap) s = cap;
