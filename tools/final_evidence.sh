@@ -30,4 +30,6 @@ cd "$R"
 } > "$O/prefill_14b_xcd_order.txt"
 timeout -k 10 200 python3 -u tools/prefill_two_streams_probe.py 1024 8 2 2> /dev/null | tail -1 > "$O/prefill_two_streams.txt"
 timeout -k 10 200 python3 -u tools/prefill_two_streams_probe.py 1024 8 4 2> /dev/null | tail -1 >> "$O/prefill_two_streams.txt"
+timeout -k 10 300 python3 -u serving_bench.py --num-requests 2048 --request-rate 2000 --random-input-len 128 --random-output-len 100 --max-num-batched-tokens 1024 --chunked-prefill --max-model-len 4096 --async-scheduling > "$O/serving_rate2000_async.txt" 2> /dev/null
+timeout -k 10 300 python3 -u serving_bench.py --num-requests 512 --request-rate 100 --random-input-len 128 --random-output-len 100 --max-num-batched-tokens 1024 --chunked-prefill --max-model-len 4096 --async-scheduling > "$O/serving_rate100_async.txt" 2> /dev/null
 ls "$O"
