@@ -68,6 +68,25 @@ struct SampleEpilogue {
     int64_t col_offset;       // first column of this (shard of the) vocabulary in the full row
 };
 
+// Tile of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id.  With xcd_strip = 8 or 4 (host: gridDim.x a
+// multiple of it) XCD i takes the i-th eighth of the tiles in an order that walks strips of that many column tiles row
+// by row, so the workgroups resident on an XCD at one time share a few column tiles of W and a few row tiles of x in
+// its L2 (Qwen3-14B shapes, 1024 rows: a prefill chunk 27.8 -> 27.15 ms; K = 1024: 2.81 -> 2.78 ms).  K-slabs (gridDim.z)
+// count as further tile rows: slab z of row tile y is row y + gridDim.y * z.
+__device__ __forceinline__ void xcd_tile(int xcd_strip, int& bx, int& by, int& bz) {
+    bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (xcd_strip) {
+        const int rows = gridDim.y * gridDim.z;
+        const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total = gridDim.x * rows;
+        const int xcd = id & 7, nl = xcd * (total >> 3) + min(xcd, total & 7) + (id >> 3);
+        const int sh = xcd_strip == 8 ? 3 : 2, per_strip = rows << sh;
+        const int strip = nl / per_strip, in = nl - strip * per_strip, row = in >> sh;
+        bx = (strip << sh) + (in & (xcd_strip - 1));
+        bz = row / (int)gridDim.y;
+        by = row - bz * (int)gridDim.y;
+    }
+}
+
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false, bool SAMPLE = false>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
@@ -89,22 +108,8 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave % WAVES_N, wm = wave / WAVES_N;
-    // Workgroups go to the 8 XCDs round-robin by linear id.  With xcd_strip = 8 or 4 (host: gridDim.x a multiple of it,
-    // any gridDim.z) XCD i takes the i-th eighth of the tiles in an order that walks strips of that many column tiles row
-    // by row, so the workgroups resident on an XCD at one time share a few column tiles of W and a few row tiles of x in
-    // its L2 (Qwen3-14B shapes, 1024 rows: a prefill chunk 27.8 -> 27.15 ms; K = 1024: no change).
-    // K-slabs (gridDim.z) count as further tile rows: slab z of row tile y is row y + gridDim.y * z.
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (xcd_strip) {
-        const int rows = gridDim.y * gridDim.z;
-        const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total = gridDim.x * rows;
-        const int xcd = id & 7, nl = xcd * (total >> 3) + min(xcd, total & 7) + (id >> 3);
-        const int sh = xcd_strip == 8 ? 3 : 2, per_strip = rows << sh;
-        const int strip = nl / per_strip, in = nl - strip * per_strip, row = in >> sh;
-        bx = (strip << sh) + (in & (xcd_strip - 1));
-        bz = row / (int)gridDim.y;
-        by = row - bz * (int)gridDim.y;
-    }
+    int bx, by, bz;
+    xcd_tile(xcd_strip, bx, by, bz);
     const int n0 = bx * BN, m0 = by * BM;
     const int kbeg = bz * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
@@ -1109,7 +1114,10 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;
         case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
-        case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;      // (eight waves on a grid of exactly 256: a 1024-token chunk 2.83 -> 2.94 ms)
+        // (one 64 x 64 tile per CU over K = 2048 / 3072, the O / down projections of a prefill chunk, as eight waves = two
+        // groups of four over alternate k-tiles whose sums meet in LDS: 11.8 / 16.1 -> 10.7 / 14.3 us alone on weights the
+        // Infinity Cache holds, 14.6 -> 14.5 us inside a chunk, where each layer's weights come from HBM: not kept)
+        case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;
         case T128x64: launch_gemm<128, 64, 2, 2, 4>(a); break;
         case T128x128: {
             // up to one workgroup per CU: nothing shares the CU's LDS, so a third stage (96 KB) keeps two tiles in
