@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
         active = min(items.seq_active[b], num_splits);
         if (split < 0) return;
     } else {                                                 // uniform grid
+        // (workgroup id = kvh + 8 * b reaches XCD id % 8: with 8 kv heads every XCD streams ONE head of all sequences.  The
+        // transposed order - the 8 heads of a sequence side by side on one XCD, whole 2-KB token rows per XCD - measured
+        // 6.49 ms against 6.29 ms per step of 256 sequences: not taken)
         split = blockIdx.x;
         b = blockIdx.z;
         num_splits = gridDim.x;
