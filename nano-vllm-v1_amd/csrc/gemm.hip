@@ -1216,7 +1216,7 @@ extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, 
                 NVH_EINVAL, "nvh_gemm_qkv_rope_store: 16-byte alignment required");
     static const bool no_fuse = getenv("NVH_NO_FUSED_QKV") != nullptr;            // A/B switch for measurements
     if (M > 0 && !no_fuse && K > 0 && K % BK == 0 && M < (1 << 30) && x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w) &&
-        pick_tile(M, N, 1) == T128x128 && nvh_cdiv(M, 128) * nvh_cdiv(N, 128) <= 256) {   // one workgroup per CU: the epilogue's registers cost no occupancy
+        pick_tile(M, N, 1) == T128x128 && nvh_cdiv(M, 128) * nvh_cdiv(N, 128) <= 256) {   // one workgroup per CU: the epilogue's registers cost no occupancy (two per CU, the Qwen3-14B shape's 448 tiles: a chunk 27.1 -> 28.9 ms)
         const bool store = k_cache && slot_mapping;
         QkvEpilogue qe{(const bf16*)q_norm_weight, (const bf16*)k_norm_weight, positions, cos_sin, store ? (bf16*)k_cache : nullptr,
                        store ? (bf16*)v_cache : nullptr, store ? slot_mapping : nullptr, eps, (int)num_q_heads, (int)num_kv_heads, (int)raw_rows};
