@@ -112,6 +112,14 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     xcd_tile(xcd_strip, bx, by, bz);
     const int n0 = bx * BN, m0 = by * BM;
     const int kbeg = bz * k_per_split;
+    // QKV epilogue: the positions of this thread's tokens, requested before the main loop, so that the epilogue waits for
+    // ONE memory latency (the cos / sin rows they select) instead of two in a row
+    constexpr int QPASSES = QKV ? BM / (NW * 4) : 1;
+    int64_t qpos[QPASSES];
+    if constexpr (QKV) {
+#pragma unroll
+        for (int p = 0; p < QPASSES; ++p) qpos[p] = qe.positions[min(m0 + p * NW * 4 + (tid >> 4), M - 1)];
+    }
     const int kend = min(K, kbeg + k_per_split);
     const int ntiles = max(0, (kend - kbeg) / BK);
 
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         if (normed) {
 #pragma unroll
             for (int p = 0; p < BM / RPP; ++p) {
-                const float* cs_row = qe.cos_sin + qe.positions[min(m0 + p * RPP + rr, M - 1)] * 128 + 8 * (c & 7);
+                const float* cs_row = qe.cos_sin + qpos[p] * 128 + 8 * (c & 7);
                 cs[p][0] = *reinterpret_cast<const f32x4*>(cs_row);
                 cs[p][1] = *reinterpret_cast<const f32x4*>(cs_row + 4);
                 cs[p][2] = *reinterpret_cast<const f32x4*>(cs_row + 64);
