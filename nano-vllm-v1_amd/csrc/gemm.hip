@@ -120,6 +120,23 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
 #pragma unroll
         for (int p = 0; p < QPASSES; ++p) qpos[p] = qe.positions[min(m0 + p * NW * 4 + (tid >> 4), M - 1)];
     }
+    // ... and, in the eight-wave form (registers to spare), the cos / sin rows themselves right after the first stages' DMA
+    constexpr bool CS_EARLY = QKV && NW == 8;
+    f32x4 cs_pre[CS_EARLY ? QPASSES : 1][4];
+    auto request_cs = [&]() {
+        if constexpr (CS_EARLY) {
+            if ((n0 >> 7) < qe.hq + qe.hkv) {                    // block-uniform: a q or k head
+#pragma unroll
+                for (int p = 0; p < QPASSES; ++p) {
+                    const float* cs_row = qe.cos_sin + qpos[p] * 128 + 8 * (tid & 7);
+                    cs_pre[p][0] = *reinterpret_cast<const f32x4*>(cs_row);
+                    cs_pre[p][1] = *reinterpret_cast<const f32x4*>(cs_row + 4);
+                    cs_pre[p][2] = *reinterpret_cast<const f32x4*>(cs_row + 64);
+                    cs_pre[p][3] = *reinterpret_cast<const f32x4*>(cs_row + 68);
+                }
+            }
+        }
+    };
     const int kend = min(K, kbeg + k_per_split);
     const int ntiles = max(0, (kend - kbeg) / BK);
 
@@ -207,6 +224,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
             asm volatile("" ::: "memory");
         };
         for (int t = 0; t < AHEAD && t < ntiles; ++t) stage(t);
+        request_cs();                                            // younger than the stages: the counted waits below only get stricter while these are in flight
         wait_tiles_in_flight<PW, (AHEAD > 0 ? AHEAD - 1 : 0)>(min(AHEAD - 1, ntiles - 1));
         if (second_half) phase_barrier();
         for (int t = 0; t < ntiles; ++t) {
@@ -318,7 +336,12 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         // cos / sin rows of this thread's 8 tokens: requested before the tile goes through LDS, so their latency
         // (position, then table row) hides behind the staging
         f32x4 cs[BM / RPP][4];
-        if (normed) {
+        if constexpr (CS_EARLY) {
+#pragma unroll
+            for (int p = 0; p < BM / RPP; ++p)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cs[p][u] = cs_pre[p][u];
+        } else if (normed) {
 #pragma unroll
             for (int p = 0; p < BM / RPP; ++p) {
                 const float* cs_row = qe.cos_sin + qpos[p] * 128 + 8 * (c & 7);
