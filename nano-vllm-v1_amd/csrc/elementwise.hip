@@ -108,6 +108,17 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
     bf16x8 wv_pre[MAXC];                                  // requested ahead of the rows: no second trip to memory after the reduction
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) wv_pre[i] = *reinterpret_cast<const bf16x8*>(w + min(lane_in_row + i * LPR, nchunk - 1) * 8);
+    // every chunk of the row (and of the residual) requested before the first one is used: loads inside the per-chunk
+    // condition below would be waited for one chunk after the other (clamped index: past the row's end a lane re-reads
+    // the last chunk and drops it).  1024 rows of 1024: 5.1 -> 4.8 us per launch.  (The slabs requested the same way, all
+    // chunks of a group of four slabs at once: no change at 256 rows, not kept.)
+    bf16x8 x_pre[PARTIALS ? 1 : MAXC], r_pre[ADD ? MAXC : 1];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int cc = min(lane_in_row + i * LPR, nchunk - 1);
+        if constexpr (!PARTIALS) x_pre[i] = *reinterpret_cast<const bf16x8*>(x + r * x_stride + cc * 8);
+        if constexpr (ADD) r_pre[i] = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + cc * 8);
+    }
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = lane_in_row + i * LPR;
@@ -147,12 +158,12 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = bf2f(f2bf((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])));   // GEMM output rounds to bf16
             } else {
-                bf16x8 t = *reinterpret_cast<const bf16x8*>(x + r * x_stride + c * 8);
+                const bf16x8 t = x_pre[PARTIALS ? 0 : i];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = bf2f(t[j]);
             }
             if constexpr (ADD) {
-                bf16x8 t = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + c * 8);
+                const bf16x8 t = r_pre[ADD ? i : 0];
                 bf16x8 nr;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(
 // chip (17 us per call at 3 split-K slabs); here the same call is 4 waves per row with a quarter of the loads each.
 // Same arithmetic per element (slab p -> partial sum p mod 4, total (s0 + s1) + (s2 + s3), one bf16 rounding);
 // the sum of squares is reduced per wave, then (w0 + w1) + (w2 + w3).
-template <int MAXC, bool ADD, bool PARTIALS>
+template <int MAXC, bool ADD, bool PARTIALS, bool UPFRONT>
 __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(
     const bf16* __restrict__ x, int64_t x_stride, bf16* __restrict__ residual, const bf16* __restrict__ w,
     bf16* __restrict__ y, int64_t y_stride, int64_t rows, int dim, float eps, const float* __restrict__ partials,
@@ -198,6 +209,34 @@ __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(
     const int nchunk = dim >> 3;
     float v[MAXC][8];
     float ss = 0.f;
+    // Everything a thread needs of its row is requested before the first use, with clamped chunk indices (past the row's
+    // end a thread re-reads the last chunk and drops it): loads under the per-chunk condition below would be waited for
+    // one after the other - with three slabs of 5120-wide rows a chain of about ten trips to memory.  Up to four slabs
+    // (each is then one partial sum: 0 + slab, as the loop below computes it) are requested the same way with UPFRONT -
+    // decode-sized batches (Qwen3-14B shape, 8 sequences: 6.71 -> 6.57 ms per step); at 1024 rows the registers that takes
+    // cost more than the chain (a prefill chunk 27.15 -> 27.3 ms), so large batches and more slabs take the loop.
+    bf16x8 wv_pre[MAXC], x_pre[PARTIALS ? 1 : MAXC], r_pre[ADD ? MAXC : 1];
+    f32x4 s_lo[PARTIALS && UPFRONT ? MAXC : 1][4], s_hi[PARTIALS && UPFRONT ? MAXC : 1][4];
+    const bool slabs_up_front = PARTIALS && UPFRONT && num_partials <= 4;           // uniform
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int cc = min((int)threadIdx.x + i * 256, nchunk - 1);
+        wv_pre[i] = *reinterpret_cast<const bf16x8*>(w + cc * 8);
+        if constexpr (!PARTIALS) x_pre[i] = *reinterpret_cast<const bf16x8*>(x + r * x_stride + cc * 8);
+        if constexpr (ADD) r_pre[i] = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + cc * 8);
+        if constexpr (PARTIALS) {
+            if (slabs_up_front) {
+                const float* src0 = partials + r * (int64_t)dim + cc * 8;
+                const int64_t slab = rows * (int64_t)dim;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* src = src0 + min(u, num_partials - 1) * slab;
+                    s_lo[i][u] = *reinterpret_cast<const f32x4*>(src);
+                    s_hi[i][u] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = threadIdx.x + i * 256;
@@ -205,33 +244,45 @@ __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(
             float xv[8];
             if constexpr (PARTIALS) {
                 float acc[4][8];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
-                }
-                const float* src0 = partials + r * (int64_t)dim + c * 8;
-                const int64_t slab = rows * (int64_t)dim;
-                for (int p = 0; p < num_partials; p += 4) {
+                if (slabs_up_front) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        if (p + u < num_partials) {
-                            const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab);
-                            const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab + 4);
+                        const bool on = u < num_partials;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { acc[u][j] += a[j]; acc[u][4 + j] += b[j]; }
+                        for (int j = 0; j < 4; ++j) {
+                            acc[u][j] = on ? 0.f + s_lo[i][u][j] : 0.f;
+                            acc[u][4 + j] = on ? 0.f + s_hi[i][u][j] : 0.f;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
+                    }
+                    const float* src0 = partials + r * (int64_t)dim + c * 8;
+                    const int64_t slab = rows * (int64_t)dim;
+                    for (int p = 0; p < num_partials; p += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (p + u < num_partials) {
+                                const f32x4 a = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab);
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(src0 + (p + u) * slab + 4);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { acc[u][j] += a[j]; acc[u][4 + j] += b[j]; }
+                            }
                         }
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = bf2f(f2bf((acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j])));
             } else {
-                bf16x8 t = *reinterpret_cast<const bf16x8*>(x + r * x_stride + c * 8);
+                const bf16x8 t = x_pre[PARTIALS ? 0 : i];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = bf2f(t[j]);
             }
             if constexpr (ADD) {
-                bf16x8 t = *reinterpret_cast<const bf16x8*>(residual + r * (int64_t)dim + c * 8);
+                const bf16x8 t = r_pre[ADD ? i : 0];
                 bf16x8 nr;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -256,7 +307,7 @@ __global__ __launch_bounds__(256) void rmsnorm_wide_kernel(
     for (int i = 0; i < MAXC; ++i) {
         const int c = threadIdx.x + i * 256;
         if (c < nchunk) {
-            bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c * 8);
+            const bf16x8 wv = wv_pre[i];
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = f2bf(bf2f(f2bf(v[i][j] * inv)) * bf2f(wv[j]));
@@ -282,11 +333,17 @@ static int32_t launch_rmsnorm(const bf16* x, int64_t xs, bf16* res, const bf16* 
         else
             rmsnorm_kernel<64, 2, ADD, PARTIALS><<<nvh_cdiv(rows, 4), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 2048) {
-        rmsnorm_wide_kernel<1, ADD, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        if (rows <= 256) rmsnorm_wide_kernel<1, ADD, PARTIALS, true><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        else rmsnorm_wide_kernel<1, ADD, PARTIALS, false><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 4096) {
-        rmsnorm_wide_kernel<2, ADD, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        if (rows <= 256) rmsnorm_wide_kernel<2, ADD, PARTIALS, true><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        else rmsnorm_wide_kernel<2, ADD, PARTIALS, false><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+    } else if (dim <= 6144) {
+        if (rows <= 256) rmsnorm_wide_kernel<3, ADD, PARTIALS, true><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        else rmsnorm_wide_kernel<3, ADD, PARTIALS, false><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else {
-        rmsnorm_wide_kernel<4, ADD, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        if (rows <= 256) rmsnorm_wide_kernel<4, ADD, PARTIALS, true><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
+        else rmsnorm_wide_kernel<4, ADD, PARTIALS, false><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     }
     NVH_CHECK_LAUNCH("rmsnorm");
     return NVH_OK;
