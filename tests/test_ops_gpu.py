@@ -379,7 +379,8 @@ def test_gemm_k_slabs_on_the_256_tile(ops, m, n, k, s):
 
 @pytest.mark.parametrize("m,inter,k", [(1, 3072, 1024), (20, 512, 256), (256, 3072, 1024), (1024, 3072, 1024), (70, 96, 192),
                                        (3, 13312, 128), (16, 17408, 64), (48, 3072, 256),    # 16x64 tile (832 / 1088 narrow tiles)
-                                       (1024, 8192, 256), (1024, 8704, 128)])                # 256x256 eight-wave tile; with a remainder launch
+                                       (1024, 8192, 256), (1024, 8704, 128),                 # 256x256 eight-wave tile; with a remainder launch
+                                       (900, 3072, 256), (1024, 3072, 1600)])                # eight-wave 128x192 tiles with ragged rows; 128x96 tiles (K beyond the 192-wide rule)
 def test_gemm_swiglu_epilogue_bit_identical_to_separate_kernels(ops, m, inter, k):
     x, w = rnd(m, k, seed=m + 1), rnd(2 * inter, k, seed=k + 2, scale=0.05)
     xd, wd = dev(x), dev(w)
