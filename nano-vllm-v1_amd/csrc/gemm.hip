@@ -475,6 +475,125 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     }
 }
 
+// ------------------------------------------------------------------ 64 x 64 tiles, two wave groups over alternate k-tiles
+// A grid of one 64 x 64 tile per CU (the O / down projections of a prefill chunk, the QKV projection of 256 decode rows)
+// leaves every SIMD with ONE wave whose LDS reads and MFMAs of a k-tile run one after the other; two such workgroups
+// on a CU take 1.3-1.4 times as long for twice the work.  Here a workgroup is eight waves = two groups of four: a stage
+// holds TWO k-tiles, group g multiplies tile 2t + g (32 x 32 per wave, the operand reuse of the four-wave tile), one
+// barrier per pair, and the groups' sums meet in LDS at the end: group 0's + group 1's, so NOT the sequential-k sum of the
+// other tiles (within the GEMM tolerance of it; no caller compares these shapes bit for bit with another route).
+// Alone, on weights the Infinity Cache holds: 1024 x 1024 x 2048 / 3072 11.8 / 16.1 -> 10.7 / 14.3 us; inside a step,
+// where every XCD pulls x and W through its own L2 first: a prefill chunk 2.745 -> 2.736 ms, a decode step of 256
+// sequences 6.251 -> 6.240 ms.
+template <int STAGES>
+__global__ __launch_bounds__(512) void gemm_kgroups_bf16_nt_kernel(const bf16* __restrict__ x, int64_t x_stride,
+                                                                   const bf16* __restrict__ w, const bf16* __restrict__ bias,
+                                                                   bf16* __restrict__ y, int64_t y_stride, int M, int N, int K,
+                                                                   int xcd_strip) {
+    constexpr int BM = 64, BN = 64, NW = 8, TN = 2, TM = 2;
+    constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, TILE_BYTES = A_BYTES + B_BYTES, STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int GROUPS8 = BN / 8 + BM / 8;
+    constexpr int PW = 2 * GROUPS8 / NW;
+    constexpr int AHEAD = STAGES - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3, wn = w4 & 1, wm = w4 >> 1;
+    int bx, by, bz;
+    xcd_tile(xcd_strip, bx, by, bz);
+    const int n0 = bx * BN, m0 = by * BM;
+    const int nstages = K / (2 * BK);
+    const int dma_r = lane >> 3, dma_pos = lane & 7;
+    const bf16* src_row[PW];
+    int lds_off[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int p = wave + i * NW;
+        const int half = p / GROUPS8, q = p % GROUPS8;
+        const bool is_b = q >= BN / 8;
+        const int g8 = is_b ? q - BN / 8 : q;
+        const int r = g8 * 8 + dma_r;
+        const int chunk = dma_pos ^ ((r >> 1) & 7);
+        if (is_b) src_row[i] = x + (int64_t)min(m0 + r, M - 1) * x_stride + chunk * 8 + half * BK;
+        else src_row[i] = w + (int64_t)min(n0 + r, N - 1) * K + chunk * 8 + half * BK;
+        lds_off[i] = half * TILE_BYTES + (is_b ? A_BYTES : 0) + g8 * 1024;
+    }
+    auto stage = [&](int t) {
+        const int k0 = t * 2 * BK;
+        char* base = smem + (t % STAGES) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src_row[i] + k0), (LDS_AS void*)(base + lds_off[i]), 16, 0, 0);
+    };
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int t = 0; t < AHEAD && t < nstages; ++t) stage(t);
+    for (int t = 0; t < nstages; ++t) {
+        wait_tiles_in_flight<PW, (AHEAD > 0 ? AHEAD - 1 : 0)>(min(AHEAD - 1, nstages - 1 - t));
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + AHEAD < nstages) stage(t + AHEAD);
+        const char* a_base = smem + (t % STAGES) * STAGE_BYTES + grp * TILE_BYTES;
+        const char* b_base = a_base + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TN], bfr[TM];
+            const int kc = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * 32 + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(a_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int r = wm * 32 + j * 16 + fr;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_base + r * 128 + ((kc ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) red[(w4 * TN * TM + i * TM + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int n = n0 + wn * 32 + i * 16 + fq * 4;
+        if (n >= N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias != nullptr) {
+            const bf16x4 b4 = *reinterpret_cast<const bf16x4*>(bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = bf2f(b4[e]);
+        }
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * 32 + j * 16 + fr;
+            if (m >= M) continue;
+            const f32x4 other = red[(w4 * TN * TM + i * TM + j) * 64 + lane];
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf((acc[i][j][e] + other[e]) + bv[e]);
+            *reinterpret_cast<bf16x4*>(y + (int64_t)m * y_stride + n) = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ residual add + RMSNorm in the GEMM's prologue
 // Decode batches: the add + RMSNorm launch in front of a projection moves a few KB and costs a whole dependent
 // launch.  Here every workgroup derives the normalised rows itself - same arithmetic, lane for lane, as
@@ -909,6 +1028,20 @@ void launch_gemm_nt(const GemmArgs& a) {
                                                        a.qkv ? *a.qkv : QkvEpilogue{}, wide, a.sample ? *a.sample : SampleEpilogue{}, xcd_strip);
 }
 
+void launch_gemm_kgroups(const GemmArgs& a) {
+    constexpr int STAGES = 3, smem = STAGES * 2 * (64 + 64) * 128;
+    static bool configured = false;
+    auto kern = gemm_kgroups_bf16_nt_kernel<STAGES>;
+    if (!configured) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        configured = true;
+    }
+    dim3 grid((unsigned)nvh_cdiv(a.N, 64), (unsigned)nvh_cdiv(a.M, 64), 1);
+    static const bool no_xcd = getenv("NVH_GEMM_NO_XCD") != nullptr;
+    const int xcd_strip = (no_xcd || grid.y == 1 || a.M < 512) ? 0 : grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 0;   // as launch_gemm_nt
+    kern<<<grid, 512, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M, a.N, a.K, xcd_strip);
+}
+
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
 void launch_gemm(const GemmArgs& a) {
     static const bool no_nt = getenv("NVH_GEMM_NO_NT") != nullptr;   // A/B switch for tuning
@@ -1145,10 +1278,14 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T16x128: launch_gemm<16, 128, 4, 1, 4>(a); break;
         case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
-        // (one 64 x 64 tile per CU over K = 2048 / 3072, the O / down projections of a prefill chunk, as eight waves = two
-        // groups of four over alternate k-tiles whose sums meet in LDS: 11.8 / 16.1 -> 10.7 / 14.3 us alone on weights the
-        // Infinity Cache holds, 14.6 -> 14.5 us inside a chunk, where each layer's weights come from HBM: not kept)
-        case T64x64: launch_gemm<64, 64, 2, 2, 4>(a); break;
+        case T64x64: {
+            const int64_t tiles64 = nvh_cdiv(a.M, 64) * nvh_cdiv(a.N, 64);
+            if (getenv("NVH_GEMM_NO_KGROUPS") == nullptr && !a.swiglu && a.qkv == nullptr && a.sample == nullptr && a.split_k == 1 && a.partials == nullptr &&
+                a.y != nullptr && a.M > 64 && a.K % 128 == 0 && a.K >= 1024 && tiles64 >= 200 && tiles64 <= 256)
+                launch_gemm_kgroups(a);
+            else launch_gemm<64, 64, 2, 2, 4>(a);
+            break;
+        }
         case T128x64: launch_gemm<128, 64, 2, 2, 4>(a); break;
         case T128x128: {
             // up to one workgroup per CU: nothing shares the CU's LDS, so a third stage (96 KB) keeps two tiles in
