@@ -326,6 +326,7 @@ GEMM_SHAPES = [(1, 4096, 1024), (9, 160, 192), (16, 1024, 2048), (17, 6144, 1024
                (1024, 17408, 128), (512, 35000, 64),                       # ... whole rounds + a remainder launch on smaller tiles
                (1, 1024, 2048), (7, 1024, 3072), (17, 1024, 3072), (32, 1000, 2048), (3, 2048, 1536), (16, 1024, 4096),   # K split between the waves of a workgroup (decode O / down projections)
                (8, 5120, 1600), (16, 5120, 4352), (32, 2048, 3200), (64, 1024, 3072), (47, 1024, 2048), (3, 1000, 2048), (20, 520, 1536),   # ... wider outputs, K up to 4608, up to 64 rows
+               (1000, 1024, 2048), (256, 4096, 1024), (200, 4000, 1152),   # one 64 x 64 tile per CU over a long K: two wave groups over alternate k-tiles (ragged rows / columns)
                (520, 1536, 128), (576, 768, 64), (600, 768, 128), (1100, 1280, 192)]   # XCD-aware tile order: strips of 8 / 4 column tiles, odd and ragged row-tile counts, a tile count that 8 does not divide
 
 
@@ -354,6 +355,15 @@ def test_gemm_k_over_waves_bias_and_strided_rows(ops):
     m, n, k = 9, 1024, 3072
     x_wide = rnd(m, k + 64, seed=23)
     w, b = rnd(n, k, seed=24, scale=0.05), rnd(n, seed=25)
+    assert_gemm(ops.linear(dev(x_wide)[:, :k], dev(w), dev(b)), R.linear(x_wide[:, :k], w, b))
+
+
+def test_gemm_two_wave_groups_bias_and_strided_rows(ops):
+    """One 64 x 64 tile per CU over K >= 1024 (eight-wave workgroups, two groups over alternate k-tiles): bias and strided
+    input rows."""
+    m, n, k = 960, 1024, 1280
+    x_wide = rnd(m, k + 128, seed=26)
+    w, b = rnd(n, k, seed=27, scale=0.05), rnd(n, seed=28)
     assert_gemm(ops.linear(dev(x_wide)[:, :k], dev(w), dev(b)), R.linear(x_wide[:, :k], w, b))
 
 
