@@ -47,6 +47,14 @@ const char* nvh_last_error(void);
  * engine/model_runner.py:121-127. */
 int32_t nvh_device_check(int32_t device_index);
 
+/* Routing / measurement switches.  Every kernel choice is a function of the call's shapes; a switch overrides one such
+ * choice for A/B measurements and for tests that compare two routes (no counterpart in the reference).  Switches are
+ * read from the environment (NVH_<NAME>) once per process and only under NVH_TUNING=1; nvh_set_switch changes one at run
+ * time (value < 0: unset; name with or without the NVH_ prefix; NVH_EINVAL for an unknown name).  Not synchronised with
+ * launches in flight on other threads.  nvh_get_switch: the value, -1 when unset, -2 for an unknown name. */
+int32_t nvh_set_switch(const char* name, int64_t value);
+int64_t nvh_get_switch(const char* name);
+
 /* ---- K1: KV-cache scatter store.  layers/attention.py:34-127 (Triton store_kvcache_kernel).
  * For token t: slot = slot_mapping[t]; slot < 0 -> skipped; otherwise cache row `slot`
  * (row_elems = Hkv*D contiguous elements) <- key[t] / value[t].  num_slots bounds-checks
@@ -398,7 +406,22 @@ typedef struct {
      * this work list (nvh_attn_decode_fused_qkv_items) with decode_splits as max_ranges. */
     int64_t decode_items;
     const int32_t *decode_item_seq, *decode_item_range, *decode_seq_active, *decode_seq_chunk;
+    /* Two steps in flight (no counterpart in the reference, whose step is one chain of launches on one stream).  A
+     * caller that launches step n+1 on ANOTHER stream before step n has finished orders the two per layer instead of as
+     * a whole: step n runs with layer_events_record = s (1 or 2) and records event s[l] after the attention of layer l;
+     * step n+1 runs with layer_events_wait = s and waits for s[l] before its QKV projection and KV store of layer l.
+     * That is all the two steps share: by then step n's keys of that layer are in the cache (a later chunk of the same
+     * prompt, or a prompt that borrows its pages, reads them) and step n no longer reads a page of that layer that step
+     * n+1 may write (pages released by one step and handed to the next).  Everything else - workspace, hidden_out, the
+     * step's metadata - must be the step's own.  The two steps then fill each other's launch-latency-bound time (a
+     * 1024-token chunk of Qwen3-0.6B is ~200 dependent launches that cannot fill the chip one at a time).  0 = none.
+     * The events live in the library (nvh_qwen3_prepare_layer_events, once per device); not for use under graph capture. */
+    int32_t layer_events_wait, layer_events_record;
 } nvh_step;
+
+/* Creates the two per-layer event sets of nvh_step.layer_events_* on the CURRENT device (idempotent; the only call of
+ * the executor that creates anything - make it at start-up).  Returns the number of layers covered. */
+int32_t nvh_qwen3_prepare_layer_events(int32_t layers);
 
 int64_t nvh_qwen3_workspace_bytes(const nvh_qwen3_model* model, int64_t num_tokens, int64_t batch, int32_t decode_splits);
 /* hidden_out: bf16 [T, hidden] (the final-norm output). */

@@ -488,9 +488,9 @@ extern "C" int32_t nvh_attn_decode_suggest_splits(int64_t batch, int64_t num_kv_
     // every range less a longer chain of dependent trips.  Ranges for batches that already give every CU a workgroup
     // (tools/decode_splits_ab.sh; one range / 1024 / 2048 workgroups aimed for): 32 sequences 1.67 / 1.77 / 1.89 ms, 64
     // sequences 2.39 / 2.60 / 2.67, 128 sequences 3.95 / 3.95 / 4.22.
-    static const int64_t target = getenv("NVH_DECODE_TARGET_WGS") ? atoll(getenv("NVH_DECODE_TARGET_WGS")) : 512;   // tuning switch
+    const int64_t target = nvh_switch_or(SW_DECODE_TARGET_WGS, 512);   // tuning switch
     const int64_t wgs = batch * num_kv_heads > 0 ? batch * num_kv_heads : 1;
-    static const int64_t full = getenv("NVH_DECODE_FULL_WGS") ? atoll(getenv("NVH_DECODE_FULL_WGS")) : 256;        // tuning switch
+    const int64_t full = nvh_switch_or(SW_DECODE_FULL_WGS, 256);        // tuning switch
     int64_t want = wgs >= full ? 1 : nvh_cdiv(target, wgs);
     const int64_t cap = max_context / 128 > 1 ? max_context / 128 : 1;
     if (want > cap) want = cap;
@@ -543,7 +543,7 @@ int32_t launch_decode(const char* name, const DecodeArgs& a, const FusedQkv& fz)
     // per step: the drain, the arrival atomic, the acquire and a merge by one workgroup cost more than the 4.7 us launch
     // they replace) and gains under 1 % at 32 sequences (1.909 against 1.926 ms).
     unsigned* arrivals = nullptr;
-    if (a.num_splits > 1 && a.batch * a.num_kv_heads <= NVH_DECODE_ARRIVALS && getenv("NVH_DECODE_MERGE_IN_LAUNCH") != nullptr) {
+    if (a.num_splits > 1 && a.batch * a.num_kv_heads <= NVH_DECODE_ARRIVALS && nvh_switch_on(SW_DECODE_MERGE_IN_LAUNCH)) {
         const int32_t rc = nvh_decode_arrivals(&arrivals);
         if (rc != NVH_OK) return rc;
     }

@@ -569,7 +569,7 @@ int rows_per_block(int g) { return g == 1 ? 128 : g == 2 ? 64 : 32; }
 // merge launch) vs 28.5; Lq 1024 / Lk 4096 in 2 ranges: 72.1 vs 58.1; 8 x 128 tokens: 10.0 vs 11.1 (nothing to share out);
 // 16 queries x 4 sequences over 4096 keys in many ranges: 26.4 vs 34.5.
 int key_groups(int g, int64_t wgs, int64_t total_q, int64_t max_seqlen_k) {
-    static const int force = getenv("NVH_ATTN_KS") ? atoi(getenv("NVH_ATTN_KS")) : 0;      // A/B switch for measurements
+    const int force = (int)nvh_switch_or(SW_ATTN_KS, 0);      // A/B switch for measurements
     if (g != 1 && g != 2 && g != 4) return 1;
     if (force == 1 || force == 2) return force;
     return (wgs <= 384 && total_q > 256 && max_seqlen_k >= 512) ? 2 : 1;
@@ -594,7 +594,7 @@ extern "C" int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch
         s = (256 + blocks / 2) / (blocks > 0 ? blocks : 1);     // nearest count to one workgroup per CU
         // from 6144 keys (where the launch walks its grid kv-head-major) four ranges: 8192 keys 85-88 us against 88-93 us in
         // two; the chunks 6-8 of an 8192-token prompt 4.02 / 4.26 / 4.57 -> 3.96 / 4.18 / 4.47 ms
-        static const int64_t long_s = getenv("NVH_VARLEN_LONG_SPLITS") ? atoll(getenv("NVH_VARLEN_LONG_SPLITS")) : 4;   // tuning switch
+        const int64_t long_s = nvh_switch_or(SW_VARLEN_LONG_SPLITS, 4);   // tuning switch
         if (max_seqlen_k >= 6144 && s < long_s) s = long_s;
         cap = tiles / 16;                                      // at least 1024 keys per range
     }
@@ -639,7 +639,7 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
     // 22.1, 8192 keys 128.1 vs 127.6; 2 x 512 x 512: 15.3 vs 13.4; 8 x 128 x 128: 9.35 vs 8.97; in two key ranges 2048 keys
     // 35.3 vs 38.2, 4096 keys 52.6 vs 53.8, 8192 keys 93.3 vs 87.8 (four ranges 91.1 vs 85.0): head-major unless a cut
     // launch has fewer than 6144 keys (NVH_ATTN_HEAD_MAJOR=0 / 1 forces one order for measurements).
-    static const int force_hm = getenv("NVH_ATTN_HEAD_MAJOR") ? atoi(getenv("NVH_ATTN_HEAD_MAJOR")) : -1;
+    const int force_hm = (int)nvh_switch(SW_ATTN_HEAD_MAJOR);
     a.head_major = force_hm >= 0 ? force_hm : (num_splits == 1 || max_seqlen_k >= 6144);
     if (nvh_cdiv(max_seqlen_q, 32) > 65535) a.head_major = 0;          // the query blocks would not fit gridDim.y
 #define LAUNCH_VL(GG, RBB, KSS, STG)                                                                                        \
@@ -656,7 +656,7 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
         case 2: {
             // a grid that leaves half the CUs without a workgroup (one 1024-token chunk: 16 blocks x 8 kv heads): 32-row
             // blocks put a four-wave workgroup on every CU instead of an eight-wave one on every other
-            static const int rb1 = getenv("NVH_ATTN_RB1") ? atoi(getenv("NVH_ATTN_RB1")) : 128;     // A/B switch: 0 = never
+            const int rb1 = (int)nvh_switch_or(SW_ATTN_RB1, 128);     // A/B switch: 0 = never
             if (ks == 2 && wgs <= rb1) LAUNCH_VL(2, 1, 2, 2);
             else if (ks == 2) LAUNCH_VL(2, 2, 2, 2);
             else LAUNCH_VL(2, 2, 1, 2);

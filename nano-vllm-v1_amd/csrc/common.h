@@ -49,6 +49,29 @@ int32_t nvh_noalloc_scratch(float** out);
 // launch (resolved on first use, or by nvh_device_check before a graph capture).
 int32_t nvh_decode_arrivals(unsigned** out);
 
+// Routing and measurement switches.  Every kernel choice in this library is a pure function of the call's shapes; the
+// switches below exist for A/B measurements and for tests that compare two routes.  They are read from the environment
+// (variable NVH_<name>) ONCE per process, and only when NVH_TUNING=1 is set, so that a stray variable in a user's
+// environment cannot change routing; afterwards only nvh_set_switch() changes them.  A switch is either unset (-1) or holds
+// a non-negative value (a variable that is set to something that is not a number counts as 1).
+#define NVH_SWITCHES(X)                                                                                              \
+    X(DECODE_TARGET_WGS) X(DECODE_FULL_WGS) X(DECODE_MERGE_IN_LAUNCH) X(ATTN_KS) X(VARLEN_LONG_SPLITS)             \
+    X(ATTN_HEAD_MAJOR) X(ATTN_RB1) X(NORM_NO_WIDE) X(GEMM_NO_WIDE_STORE) X(GEMM_NO_XCD) X(GEMM_NO_NT)              \
+    X(GEMM_NO_SKINNY) X(GEMM_M32_SKINNY) X(GEMM_FORCE_TILE) X(GEMM_NO_256) X(NO_KWAVES) X(KWAVES_KMIN)             \
+    X(KWAVES_NO_8) X(GEMM_S128) X(GEMM_S64) X(GEMM_NO_ROUND_CUT) X(GEMM_NO_16x64) X(GEMM_NO_KGROUPS)               \
+    X(QKV_NO_8WAVE) X(SWIGLU_NO_192) X(SWIGLU_NO_96) X(NO_FUSED_QKV) X(NO_NORM_GEMM) X(NORM_GEMM_KB)               \
+    X(NORM_GEMM_ROWS) X(DECODE_SLABS) X(NO_FUSED_EXCHANGE) X(NO_FUSED_DECODE)        \
+    X(LM_HEAD_NO_CUT) X(EXP_A) X(EXP_B)
+enum NvhSwitch : int {
+#define NVH_SW_ENUM(n) SW_##n,
+    NVH_SWITCHES(NVH_SW_ENUM)
+#undef NVH_SW_ENUM
+    SW_COUNT
+};
+int64_t nvh_switch(NvhSwitch s);                                   // -1: unset
+static inline bool nvh_switch_on(NvhSwitch s) { return nvh_switch(s) >= 0; }
+static inline int64_t nvh_switch_or(NvhSwitch s, int64_t dflt) { const int64_t v = nvh_switch(s); return v >= 0 ? v : dflt; }
+
 static inline bool nvh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int64_t nvh_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

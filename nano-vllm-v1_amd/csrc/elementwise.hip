@@ -325,7 +325,7 @@ static int32_t launch_rmsnorm(const bf16* x, int64_t xs, bf16* res, const bf16* 
         rmsnorm_kernel<16, 1, ADD, PARTIALS><<<nvh_cdiv(rows, 16), 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
     } else if (dim <= 1024) {
         // decode-sized batches: one wave per workgroup, so a few hundred rows still reach every CU
-        static const bool no_wide = getenv("NVH_NORM_NO_WIDE") != nullptr;      // A/B switch for measurements
+        const bool no_wide = nvh_switch_on(SW_NORM_NO_WIDE);      // A/B switch for measurements
         if (PARTIALS && rows <= 64 && np >= 8 && !no_wide)
             rmsnorm_kernel<64, 2, ADD, PARTIALS, 256, PARTIALS><<<(unsigned)rows, 256, 0, st>>>(x, xs, res, w, y, ys, rows, (int)dim, eps, partials, np);
         else if (rows <= 512)               // (1024 rows: 2.907 -> 2.892 ms per prefill chunk with four rows per workgroup; 1 / 2 / 8 rows: 2.721 / 2.719 / 2.721 against 2.710 ms)

@@ -1017,12 +1017,12 @@ void launch_gemm_nt(const GemmArgs& a) {
         configured = true;
     }
     const int ktiles = a.K / BK;
-    static const bool no_wide = getenv("NVH_GEMM_NO_WIDE_STORE") != nullptr;   // A/B switch for measurements
+    const bool no_wide = nvh_switch_on(SW_GEMM_NO_WIDE_STORE);   // A/B switch for measurements
     // wide stores need 16-byte aligned output rows and the staging tile inside the kernel's LDS
     const bool wide = !no_wide && a.ys % 8 == 0 && nvh_aligned16(a.y) && smem >= BM * 136 * 2;
     const int k_per_split = (int)nvh_cdiv(ktiles, a.split_k) * BK;
     dim3 grid((unsigned)nvh_cdiv(a.N, BN), (unsigned)nvh_cdiv(a.M, BM), (unsigned)a.split_k);
-    static const bool no_xcd = getenv("NVH_GEMM_NO_XCD") != nullptr;            // A/B switch for measurements
+    const bool no_xcd = nvh_switch_on(SW_GEMM_NO_XCD);            // A/B switch for measurements
     // prefill-sized products only: at 256 rows (a decode batch, 64-row tiles) the same order made a step 0.7 % slower
     const int xcd_strip = (no_xcd || grid.y * grid.z == 1 || a.M < 512) ? 0 : grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 0;
     kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split,
@@ -1038,14 +1038,14 @@ void launch_gemm_kgroups(const GemmArgs& a) {
         configured = true;
     }
     dim3 grid((unsigned)nvh_cdiv(a.N, 64), (unsigned)nvh_cdiv(a.M, 64), 1);
-    static const bool no_xcd = getenv("NVH_GEMM_NO_XCD") != nullptr;
+    const bool no_xcd = nvh_switch_on(SW_GEMM_NO_XCD);
     const int xcd_strip = (no_xcd || grid.y == 1 || a.M < 512) ? 0 : grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 0;   // as launch_gemm_nt
     kern<<<grid, 512, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M, a.N, a.K, xcd_strip);
 }
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
 void launch_gemm(const GemmArgs& a) {
-    static const bool no_nt = getenv("NVH_GEMM_NO_NT") != nullptr;   // A/B switch for tuning
+    const bool no_nt = nvh_switch_on(SW_GEMM_NO_NT);   // A/B switch for tuning
     const bool nt = a.M <= BM && !no_nt;
     if constexpr (BM == 128 && BN == 128 && WAVES_N == 2 && (WAVES_M == 2 || WAVES_M == 4)) {
         if (a.qkv) {
@@ -1074,16 +1074,16 @@ enum Tile { T16x32, T32x32, T16x128, T32x128, T64x128, T64x64, T128x64, T128x128
 Tile pick_tile(int64_t M, int64_t N, int split_k) {
     // decode batches: 128-row weight tiles leave most CUs idle unless the output is very wide; 32-row tiles in
     // two-wave workgroups (three fit a CU) keep the weight stream spread over the chip
-    static const bool no_skinny = getenv("NVH_GEMM_NO_SKINNY") != nullptr;
+    const bool no_skinny = nvh_switch_on(SW_GEMM_NO_SKINNY);
     const bool narrow = nvh_cdiv(N, 128) * split_k < 384 && !no_skinny;
     if (M <= 16) return narrow ? T16x32 : T16x128;
-    static const bool m32_skinny = getenv("NVH_GEMM_M32_SKINNY") != nullptr;   // tuning switch
+    const bool m32_skinny = nvh_switch_on(SW_GEMM_M32_SKINNY);   // tuning switch
     if (M <= 32) return (narrow && (split_k == 1 || m32_skinny)) ? T32x32 : T32x128;      // with split-K the 128-row tile measured faster
     auto wgs = [&](int bm, int bn) { return nvh_cdiv(M, bm) * nvh_cdiv(N, bn) * split_k; };
-    static const int force = getenv("NVH_GEMM_FORCE_TILE") ? atoi(getenv("NVH_GEMM_FORCE_TILE")) : -1;   // tuning switch
+    const int force = (int)nvh_switch(SW_GEMM_FORCE_TILE);   // tuning switch
     if (force >= T16x128 && force <= T256x256) return (Tile)force;
     if (M <= 64) return nvh_cdiv(N, 128) * split_k >= 384 ? T64x128 : T64x64;   // 33..64 rows: enough workgroups first
-    static const bool no256 = getenv("NVH_GEMM_NO_256") != nullptr;
+    const bool no256 = nvh_switch_on(SW_GEMM_NO_256);
     // big products (prefill of the 14B / 32B shapes, square GEMMs from 4096 up, the LM head from 256 rows): 256 x 256
     // tiles in eight-wave workgroups once they fill the chip and few of their rows are padding (4096^3: 985 -> 1196
     // TFLOP/s; 1024 x 34816 x 5120: 705 -> 877; LM head at 256 / 512 rows: 132 -> 118 / 244 -> 215 us; 128 tiles: 983 -> 710)
@@ -1196,8 +1196,8 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
 // Only from K = 1536: below that a gate/up projection could take it, and its sum over K would no longer be the one of the
 // SwiGLU kernel (nvh_gemm_swiglu_bf16_nt promises the bits of nvh_gemm_bf16_nt + nvh_silu_mul).
 static bool takes_kwaves(const GemmArgs& a) {
-    static const bool off = getenv("NVH_NO_KWAVES") != nullptr;                   // A/B switch for measurements
-    static const int kmin = getenv("NVH_KWAVES_KMIN") ? atoi(getenv("NVH_KWAVES_KMIN")) : 1536;   // tuning switch
+    const bool off = nvh_switch_on(SW_NO_KWAVES);                   // A/B switch for measurements
+    const int kmin = (int)nvh_switch_or(SW_KWAVES_KMIN, 1536);   // tuning switch
     return !off && a.split_k == 1 && !a.swiglu && !a.qkv && !a.sample && a.M <= 64 && a.K >= kmin && a.K <= 64 * 8 * 9 &&
            nvh_cdiv(a.N, 16) * nvh_cdiv(a.M, 16) <= 384;
 }
@@ -1218,22 +1218,22 @@ static void launch_kwaves(const GemmArgs& a) {
 static int32_t dispatch_gemm(const GemmArgs& a) {
     if (takes_kwaves(a)) {
         // eight output columns per workgroup while that still leaves CUs without one
-        static const bool no8 = getenv("NVH_KWAVES_NO_8") != nullptr;             // A/B switch for measurements
+        const bool no8 = nvh_switch_on(SW_KWAVES_NO_8);             // A/B switch for measurements
         const bool narrow = !no8 && nvh_cdiv(a.N, 8) * nvh_cdiv(a.M, 16) <= 256;
         if (a.K / BK >= 32) { if (narrow) launch_kwaves<8, 8>(a); else launch_kwaves<8, 16>(a); }
         else { if (narrow) launch_kwaves<4, 8>(a); else launch_kwaves<4, 16>(a); }
         NVH_CHECK_LAUNCH("gemm_kwaves_bf16_nt");
         return NVH_OK;
     }
-    static const int s128 = getenv("NVH_GEMM_S128") ? atoi(getenv("NVH_GEMM_S128")) : 0;   // tuning switches
-    static const int s64 = getenv("NVH_GEMM_S64") ? atoi(getenv("NVH_GEMM_S64")) : 0;
+    const int s128 = (int)nvh_switch_or(SW_GEMM_S128, 0);   // tuning switches
+    const int s64 = (int)nvh_switch_or(SW_GEMM_S64, 0);
     const Tile tile = pick_tile(a.M, a.N, a.split_k);
     if (tile == T256x256 && a.split_k == 1 && !a.sample && !a.qkv) {
         // One 256 x 256 workgroup fits a CU, so the grid runs in rounds of 256 tiles and a last round with few tiles
         // costs a whole round (Qwen3-14B gate/up at 1024 rows: 544 tiles, 403 us; 512 tiles 300 us).  Columns that make
         // whole rounds go first; a remainder of at most half a round follows as a launch of its own on the tile that
         // fits IT (34 us for the 32 left-over tiles above).
-        static const bool no_cut = getenv("NVH_GEMM_NO_ROUND_CUT") != nullptr;       // A/B switch for measurements
+        const bool no_cut = nvh_switch_on(SW_GEMM_NO_ROUND_CUT);       // A/B switch for measurements
         const int64_t tm = nvh_cdiv(a.M, 256), tn = nvh_cdiv(a.N, 256);
         int64_t g = tm, r = 256;
         while (r) { const int64_t t = g % r; g = r; r = t; }                         // gcd(tm, 256)
@@ -1260,7 +1260,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T16x32: {
             // outputs a little wider than one round of 32-column workgroups (768 fit the chip): 64-column tiles put
             // them all in flight at once instead of leaving a short second round (Qwen3-14B gate/up: 1088 vs 544)
-            static const bool no64 = getenv("NVH_GEMM_NO_16x64") != nullptr;       // A/B switch for measurements
+            const bool no64 = nvh_switch_on(SW_GEMM_NO_16x64);       // A/B switch for measurements
             const int64_t t32 = nvh_cdiv(a.N, 32) * a.split_k, t64 = nvh_cdiv(a.N, 64) * a.split_k;
             const bool wide64 = !no64 && a.M <= 16 && t32 > 768 && t64 <= 768 && (a.swiglu || t32 <= 1024);   // measured: 896 tiles 57.8 -> 49.8 us, 1088 plain 66.7 -> 68.6
             if (a.swiglu) {
@@ -1281,7 +1281,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
         case T64x64: {
             const int64_t tiles64 = nvh_cdiv(a.M, 64) * nvh_cdiv(a.N, 64);
-            if (getenv("NVH_GEMM_NO_KGROUPS") == nullptr && !a.swiglu && a.qkv == nullptr && a.sample == nullptr && a.split_k == 1 && a.partials == nullptr &&
+            if (!nvh_switch_on(SW_GEMM_NO_KGROUPS) && !a.swiglu && a.qkv == nullptr && a.sample == nullptr && a.split_k == 1 && a.partials == nullptr &&
                 a.y != nullptr && a.M > 64 && a.K % 128 == 0 && a.K >= 1024 && tiles64 >= 200 && tiles64 <= 256)
                 launch_gemm_kgroups(a);
             else launch_gemm<64, 64, 2, 2, 4>(a);
@@ -1295,7 +1295,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
             // included): eight waves (two per SIMD, one barrier apart; the QKV epilogue walks 32 rows per pass).  1024 / 896 x
             // 4096 x 1024: 16.1 / 15.1 -> 14.9 / 14.4 us, a 1024-token chunk 2.89 -> 2.81 ms; K = 2048: 25.5 -> 26.2 us (not taken)
             const int64_t tiles128 = nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k;
-            if (!a.swiglu && getenv("NVH_QKV_NO_8WAVE") == nullptr && tiles128 >= 200 && tiles128 <= 256 && a.K / a.split_k <= 1536) launch_gemm<128, 128, 2, 4, 3>(a);
+            if (!a.swiglu && !nvh_switch_on(SW_QKV_NO_8WAVE) && tiles128 >= 200 && tiles128 <= 256 && a.K / a.split_k <= 1536) launch_gemm<128, 128, 2, 4, 3>(a);
             else if (nvh_cdiv(a.M, 128) * nvh_cdiv(a.N, 128) * a.split_k <= 256) launch_gemm<128, 128, 2, 2, 3>(a);
             // gate/up + SwiGLU over a grid whose last round of 128 x 128 tiles is half empty (1024 x 6144: 384 tiles = 1.5
             // rounds of 256 CUs): 128 x 96 tiles make whole rounds (512).  Taken when rounds x tile area, the narrower tile
@@ -1303,10 +1303,10 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
             // whole rounds: 2.81; a third stage on the 96-wide tile, one resident per CU: 2.95.)
             // ... and a nearly full single round of eight-wave 128 x 192 tiles (1024 x 6144: exactly 256) ahead of both, over a
             // short K like the QKV case above: a 1024-token chunk 2.789 -> 2.771 ms
-            else if (a.swiglu && a.N % 192 == 0 && getenv("NVH_SWIGLU_NO_192") == nullptr && a.K <= 1536 && a.split_k == 1 &&
+            else if (a.swiglu && a.N % 192 == 0 && !nvh_switch_on(SW_SWIGLU_NO_192) && a.K <= 1536 && a.split_k == 1 &&
                      nvh_cdiv(a.M, 128) * (a.N / 192) >= 200 && nvh_cdiv(a.M, 128) * (a.N / 192) <= 256)
                 launch_gemm<128, 192, 2, 4, 3>(a);
-            else if (a.swiglu && a.N % 96 == 0 && getenv("NVH_SWIGLU_NO_96") == nullptr &&
+            else if (a.swiglu && a.N % 96 == 0 && !nvh_switch_on(SW_SWIGLU_NO_96) &&
                      nvh_cdiv(nvh_cdiv(a.M, 128) * (a.N / 96) * a.split_k, 256) * 96 * 105 < nvh_cdiv(tiles128, 256) * 128 * 100)
                 launch_gemm<128, 96, 1, 4, 2>(a);
             else launch_gemm<128, 128, 2, 2, 2>(a);
@@ -1383,7 +1383,7 @@ extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, 
     NVH_REQUIRE(qkv_row_stride % 8 == 0 && nvh_aligned16(qkv) && nvh_aligned16(cos_sin) && nvh_aligned16(q_norm_weight) && nvh_aligned16(k_norm_weight) &&
                     (!k_cache || (nvh_aligned16(k_cache) && nvh_aligned16(v_cache))),
                 NVH_EINVAL, "nvh_gemm_qkv_rope_store: 16-byte alignment required");
-    static const bool no_fuse = getenv("NVH_NO_FUSED_QKV") != nullptr;            // A/B switch for measurements
+    const bool no_fuse = nvh_switch_on(SW_NO_FUSED_QKV);            // A/B switch for measurements
     if (M > 0 && !no_fuse && K > 0 && K % BK == 0 && M < (1 << 30) && x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w) &&
         pick_tile(M, N, 1) == T128x128 && nvh_cdiv(M, 128) * nvh_cdiv(N, 128) <= 256) {   // one workgroup per CU: the epilogue's registers cost no occupancy (two per CU, the Qwen3-14B shape's 448 tiles: a chunk 27.1 -> 28.9 ms)
         const bool store = k_cache && slot_mapping;
@@ -1416,13 +1416,13 @@ void launch_gemm_addnorm(const NormPrologue& np, const bf16* w, bf16* y, int64_t
 }  // namespace
 
 extern "C" int32_t nvh_add_rmsnorm_gemm_fused(int64_t M, int64_t N, int64_t K, int64_t num_slabs, int32_t swiglu) {
-    const bool off = getenv("NVH_NO_NORM_GEMM") != nullptr;                        // A/B switch for measurements and tests (read per call)
+    const bool off = nvh_switch_on(SW_NO_NORM_GEMM);                               // A/B switch for measurements and tests
     // KB a workgroup reads to derive the rows again (every workgroup of the grid does): beyond this the norm launch is cheaper
-    static const int64_t budget_kb = getenv("NVH_NORM_GEMM_KB") ? atoll(getenv("NVH_NORM_GEMM_KB")) : 128;
+    const int64_t budget_kb = nvh_switch_or(SW_NORM_GEMM_KB, 128);
     // 1: take it.  2 (33..64 rows; measured 2.6-3.7 % per decode step at 40..64 sequences): take it only where every step
     // of that size does - every row count that changes route changes the order of a few fp32 sums, and steps of 33..64
     // tokens are mostly mixed ones whose neighbours take the generic route; the step executor takes it for pure decode steps.
-    static const int64_t max_rows = getenv("NVH_NORM_GEMM_ROWS") ? atoll(getenv("NVH_NORM_GEMM_ROWS")) : 64;   // tuning switch
+    const int64_t max_rows = nvh_switch_or(SW_NORM_GEMM_ROWS, 64);   // tuning switch
     if (off || M < 1 || M > 64 || M > max_rows || K < BK || K > 1024 || K % BK != 0 || N < 1 || N >= (1 << 30) || num_slabs < 0 || num_slabs > 64) return 0;
     if (swiglu ? N % 32 != 0 : N % 4 != 0) return 0;
     // one workgroup per CU (its LDS holds the whole weight slice): beyond 32 rows only grids of one round

@@ -81,6 +81,38 @@ static int32_t decode_attention(const nvh_qwen3_model* md, const nvh_step* st, i
         if (rc__ != NVH_OK) return rc__; \
     } while (0)
 
+// ---- two steps in flight: per-layer events between consecutive steps on different streams (nvh_step.layer_events_*)
+namespace {
+constexpr int kMaxDevices = 16, kEventSets = 2, kMaxEventLayers = 128;
+struct LayerEvents {
+    hipEvent_t ev[kEventSets][kMaxEventLayers];
+    int layers = 0;                      // 0: not prepared
+};
+LayerEvents g_layer_events[kMaxDevices];
+
+#define HIPCHK(call, what)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (call);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            nvh_set_error("%s: %s", what, hipGetErrorString(e__));                      \
+            return NVH_ELAUNCH;                                                         \
+        }                                                                               \
+    } while (0)
+}  // namespace
+
+extern "C" int32_t nvh_qwen3_prepare_layer_events(int32_t layers) {
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev), "nvh_qwen3_prepare_layer_events: hipGetDevice");
+    NVH_REQUIRE(dev >= 0 && dev < kMaxDevices, NVH_EINVAL, "nvh_qwen3_prepare_layer_events: device %d out of range", dev);
+    NVH_REQUIRE(layers >= 1 && layers <= kMaxEventLayers, NVH_EINVAL, "nvh_qwen3_prepare_layer_events: %d layers (1..%d)", layers, kMaxEventLayers);
+    LayerEvents& L = g_layer_events[dev];
+    for (int l = L.layers; l < layers; ++l) {
+        for (int s = 0; s < kEventSets; ++s) HIPCHK(hipEventCreateWithFlags(&L.ev[s][l], hipEventDisableTiming), "nvh_qwen3_prepare_layer_events: event");
+        L.layers = l + 1;
+    }
+    return L.layers;
+}
+
 // The step is a chain of parts separated by the sums over the tensor-parallel ranks:
 //   part 0            embedding                                        (its sum: the residual stream)
 //   part 2l+1         layer l: input norm .. O projection             (its sum: the projection output)
@@ -112,7 +144,18 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
                 (long)workspace_bytes, (long)w.total);
     NVH_REQUIRE(st->mode == NVH_MODE_PACKED || st->block_tables, NVH_EINVAL, "nvh_qwen3_forward: paged modes need block_tables");
     NVH_REQUIRE(st->mode != NVH_MODE_DECODE || (st->context_lens && t == b), NVH_EINVAL, "nvh_qwen3_forward: decode mode needs context_lens and one token per sequence");
-
+    // Two steps in flight (see nvh_step.layer_events_wait): this step's event sets on the current device
+    hipEvent_t *ev_wait = nullptr, *ev_record = nullptr;
+    if (st->layer_events_wait || st->layer_events_record) {
+        int dev = -1;
+        NVH_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices && g_layer_events[dev].layers >= md->layers, NVH_EINVAL,
+                    "nvh_qwen3_forward: layer events asked for but not prepared (nvh_qwen3_prepare_layer_events)");
+        NVH_REQUIRE(st->layer_events_wait >= 0 && st->layer_events_wait <= kEventSets && st->layer_events_record >= 0 &&
+                        st->layer_events_record <= kEventSets && (st->layer_events_wait == 0 || st->layer_events_wait != st->layer_events_record),
+                    NVH_EINVAL, "nvh_qwen3_forward: layer event sets %d / %d", st->layer_events_wait, st->layer_events_record);
+        if (st->layer_events_wait) ev_wait = g_layer_events[dev].ev[st->layer_events_wait - 1];
+        if (st->layer_events_record) ev_record = g_layer_events[dev].ev[st->layer_events_record - 1];
+    }
     const int64_t h = md->hidden, d = md->head_dim, hq = md->num_q_heads, hkv = md->num_kv_heads;
     const int64_t qsz = hq * d, kvsz = hkv * d, qkv_n = qsz + 2 * kvsz;
     const float scale = 1.0f / sqrtf((float)d);
@@ -120,7 +163,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     const bool sharded = md->comm || external;
     // decode batches whose add + norm happens in the next projection's prologue: no slabs either (every workgroup of
     // that projection would sum them again); the O / down projections then split K between the waves of a workgroup
-    const bool no_full_k = getenv("NVH_DECODE_SLABS") != nullptr;                 // A/B switch for measurements and tests (read per call)
+    const bool no_full_k = nvh_switch_on(SW_DECODE_SLABS);                        // A/B switch for measurements and tests
     // (an answer of 2 - 33..64 rows - only for pure decode steps: every decode step of that size then takes the same route)
     const int32_t fused_limit = st->mode == NVH_MODE_DECODE ? 2 : 1;
     auto fused_ok = [&](int64_t n, int64_t slabs, int32_t swiglu) {
@@ -140,7 +183,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     }
     // decode-sized messages: the sum, the residual add and the norm are one kernel; larger ones keep the two-shot
     // all-reduce (less xGMI traffic) followed by the norm
-    static const bool no_fused = getenv("NVH_NO_FUSED_EXCHANGE") != nullptr;
+    const bool no_fused = nvh_switch_on(SW_NO_FUSED_EXCHANGE);
     const bool fused_exchange = comm && !no_fused && t * h * 2 <= (int64_t)(1 << 20);
     if (runs(0)) {
         FWD(nvh_embedding(st->input_ids, md->embed, w.residual, t, h, md->vocab_start, md->vocab_rows, stream));
@@ -164,6 +207,9 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     };
     for (int l = 0; l < md->layers; ++l) {
       if (runs(2 * l + 1)) {
+        // the step before this one (on another stream) is done with the attention of this layer: its keys are in the
+        // cache, and it no longer reads a page this step's KV store may write
+        if (ev_wait) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, ev_wait[l], 0), "nvh_qwen3_forward: layer event wait");
         // ---- input norm: layer 0 normalises the embedding; later layers add the MLP output first
         bf16* const res = residual_after(l, l);                     // input sites of layers 0..l-1, post sites of layers 0..l-1
         bool qkv_done = false;
@@ -184,7 +230,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
         void* kc = md->k_cache ? md->k_cache[l] : nullptr;
         void* vc = md->v_cache ? md->v_cache[l] : nullptr;
         const bool store = kc && vc && st->slot_mapping;
-        static const bool fuse_decode = getenv("NVH_NO_FUSED_DECODE") == nullptr;   // A/B switch for measurements
+        const bool fuse_decode = !nvh_switch_on(SW_NO_FUSED_DECODE);   // A/B switch for measurements
         const bool decode_fused = st->mode == NVH_MODE_DECODE && store && fuse_decode;
         bool qk_done = false;               // the q/k epilogue and the KV store of rows prefix.. already happened
         if (qkv_done) {
@@ -227,6 +273,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
                                     nullptr, 0, b, st->max_seqlen_q, st->max_seqlen_k, t, hq, hkv, d, scale, w.attn, vsplits, w.varlen_ws, stream));
             }
         }
+        if (ev_record) HIPCHK(hipEventRecord(ev_record[l], (hipStream_t)stream), "nvh_qwen3_forward: layer event record");
         // ---- O projection
         if (so > 1) FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, nullptr, h, t, h, qsz, so, w.slabs, stream));
         else FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, proj_out, h, t, h, qsz, 1, nullptr, stream));

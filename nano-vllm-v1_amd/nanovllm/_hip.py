@@ -19,6 +19,8 @@ SIGNATURES = {
     "nvh_version": (i32, []),
     "nvh_last_error": (C.c_char_p, []),
     "nvh_device_check": (i32, [i32]),
+    "nvh_set_switch": (i32, [C.c_char_p, i64]),
+    "nvh_get_switch": (i64, [C.c_char_p]),
     "nvh_store_kvcache": (i32, [vp, i64, vp, i64, vp, vp, vp, i64, i64, vp]),
     "nvh_rmsnorm": (i32, [vp, i64, vp, vp, i64, i64, i64, f32, vp]),
     "nvh_add_rmsnorm": (i32, [vp, vp, vp, vp, i64, i64, f32, vp, i64, vp]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "nvh_sample_with_noise": (i32, [vp, i32, i64, vp, vp, vp, i64, i64, vp, vp]),
     "nvh_argmax": (i32, [vp, i32, i64, vp, i64, i64, vp, vp]),
     # struct pointers (nvh_qwen3_model*, nvh_step*) travel as void*; layouts are in nanovllm/native.py
+    "nvh_qwen3_prepare_layer_events": (i32, [i32]),
     "nvh_qwen3_workspace_bytes": (i64, [vp, i64, i64, i32]),
     "nvh_qwen3_forward": (i32, [vp, vp, vp, vp, i64, vp]),
     "nvh_qwen3_forward_parts": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
@@ -109,3 +112,22 @@ def check(code: int, what: str) -> None:
 
 def call(name: str, *args) -> None:
     check(getattr(lib(), name)(*args), name)
+
+
+class switch:
+    """``with _hip.switch("NVH_NO_NORM_GEMM"): ...`` - one routing switch of the library set for the block (value -1
+    unsets it), restored afterwards.  For tests and measurements that compare two routes inside one process."""
+
+    def __init__(self, name: str, value: int = 1):
+        self.name, self.value = name.encode(), value
+
+    def __enter__(self):
+        self.prev = lib().nvh_get_switch(self.name)
+        if self.prev == -2:
+            raise HipError(f"unknown switch {self.name.decode()}")
+        call("nvh_set_switch", self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        call("nvh_set_switch", self.name, self.prev)
+        return False

@@ -17,6 +17,7 @@ Same contract as the reference's engine/model_runner.py:49-715 -
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import sys
 import pickle
@@ -180,6 +181,16 @@ class ModelRunner:
         _hip.check(_hip.lib().nvh_device_check(device_index), "nvh_device_check")
 
         self.split_mixed = os.environ.get("NANOVLLM_SPLIT_MIXED", "1") != "0"     # A/B switch: decode prefix of mixed steps
+        # Two steps in flight (see _step): consecutive prefill-sized steps that do not wait for each other's sampled ids
+        # alternate between the caller's stream and a side stream.  For models whose launches cannot fill the chip one at
+        # a time (per-layer weights up to 64 Mi parameters: Qwen3-0.6B / 1.7B); NANOVLLM_STEP_OVERLAP=0 / 1 forces it off / on.
+        head_dim = getattr(hf, "head_dim", None) or hf.hidden_size // hf.num_attention_heads
+        layer_params = hf.hidden_size * (3 * hf.intermediate_size + 2 * (hf.num_attention_heads + hf.num_key_value_heads) * head_dim)
+        flag = os.environ.get("NANOVLLM_STEP_OVERLAP", "")
+        self.step_overlap = self.world_size == 1 and (flag == "1" or (flag != "0" and layer_params <= 64 * 2 ** 20))
+        self._side_stream = None                # created with the first step that takes it
+        self._last_step = None                  # lane, completion event and event set of the step launched last
+        self._step_depth, self._step_fb = 0, None
         self.comm = None
         if self.world_size > 1:
             # staging: the widest all-reduce (a full token budget of hidden rows) or logits gather (every sequence)
@@ -298,7 +309,7 @@ class ModelRunner:
         n = int.from_bytes(self.shm.buf[0:4], "little")
         method_name, *args = pickle.loads(self.shm.buf[4:n + 4])
         self.event.clear()
-        self._msg_seq += 1
+        self._msg_seq = (self._msg_seq + 1) & 0xFFFFFFFF                      # a 4-byte counter on both sides: wraps, never overflows
         at = SHM_BYTES - self.ACK_BYTES + 4 * self.rank
         self.shm.buf[at:at + 4] = self._msg_seq.to_bytes(4, "little")        # after the clear: the next set cannot be lost
         return method_name, args
@@ -316,7 +327,7 @@ class ModelRunner:
                 if time.perf_counter() > deadline:
                     raise RuntimeError(f"rank {r} has not taken control message {self._msg_seq} for 120 s")
                 time.sleep(0)
-        self._msg_seq += 1
+        self._msg_seq = (self._msg_seq + 1) & 0xFFFFFFFF
         self.shm.buf[0:4] = n.to_bytes(4, "little")
         self.shm.buf[4:n + 4] = data
         for event in self.event:
@@ -410,6 +421,7 @@ class ModelRunner:
             arrays["fed_dst"], arrays["fed_src"] = fed
         d = self.staging.upload(arrays)
         if fed is not None:
+            self.prev_sampled.record_stream(torch.cuda.current_stream())       # (it may come from a step on the other stream)
             ops.feed_token_ids(d["input_ids"], d["fed_dst"], self.prev_sampled, d["fed_src"])
         fb["items"] = None if plan is None else {k: d[k] for k in ("item_seq", "item_range", "seq_active", "seq_chunk")}
         fb["tails"] = (d.get("cu_seqlens_q_tail"), d.get("cu_seqlens_k_tail"))
@@ -449,7 +461,7 @@ class ModelRunner:
                                    max_seqlen_k=fb["max_seqlen_k"], slot_mapping=ctx.slot_mapping,
                                    context_lens=ctx.context_lens, block_tables=ctx.block_tables, decode_splits=splits,
                                    decode_prefix=prefix, cu_seqlens_q_tail=tails[0], cu_seqlens_k_tail=tails[1],
-                                   decode_items=items)
+                                   decode_items=items, layer_events=fb.get("layer_events", (0, 0)))
 
     def decode_buckets(self) -> list[int]:
         max_bs = min(self.config.max_num_seqs, 512)
@@ -504,15 +516,76 @@ class ModelRunner:
             return None
         return graph
 
+    OVERLAP_MIN_TOKENS = 256     # steps with fewer new tokens are not worth a second stream
+
+    @contextlib.contextmanager
+    def _step(self, seqs, join: bool = False):
+        """Everything a step enqueues happens inside this context: it flattens the batch, picks the stream the step runs
+        on and orders it against the step launched before it.
+
+        Normally that is the caller's stream and stream order.  But a prefill-sized step (a chunk of a prompt, a wave of
+        new prompts) of a small model is ~200 dependent launches that cannot fill the chip one at a time, and the next
+        such step is often launched while it is still running (chunk steps return no ids, so not even the synchronous
+        loop waits for them; the loop that runs one step ahead never does).  Two such steps in a row - eager native
+        steps of one rank that take no token from the sampler output of a step still in flight - therefore alternate
+        between the caller's stream and a side stream and fill each other's idle time.  What orders them is per layer:
+        the later step's QKV projection + KV store of layer l waits for the earlier step's attention of layer l
+        (nvh_step.layer_events_wait), which covers keys the later step reads (the next chunk of the same prompt, shared
+        prefix pages) and pages the earlier step still reads and the later one overwrites.  Every other pair of steps
+        is ordered as a whole.  `join`: the caller's stream also waits for this step (for entry points that hand device
+        tensors back to their caller)."""
+        if self._step_depth:                        # nested (run -> forward_sampled): the outer context owns the step
+            self._step_depth += 1
+            try:
+                yield self._step_fb
+            finally:
+                self._step_depth -= 1
+            return
+        fb = flatten_batch(seqs, self.block_size)
+        fb["fed"] = self._fed_indices(seqs, fb)
+        fb["graph"] = self._graph_for(fb)
+        last = self._last_step
+        eligible = (self.step_overlap and self.native is not None and self.native.layer_events and fb["graph"] is None
+                    and fb["fed"] is None and fb["max_seqlen_q"] > 1 and fb["input_ids"].size >= self.OVERLAP_MIN_TOKENS
+                    and all(len(s.block_table) for s in seqs))
+        lane, wait, record = 0, 0, 0
+        if eligible:
+            record = 1
+            if last is not None and last["record"]:
+                lane, wait, record = 1 - last["lane"], last["record"], 3 - last["record"]
+        fb["layer_events"] = (wait, record)
+        main = torch.cuda.current_stream()
+        if lane == 1 and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        stream = self._side_stream if lane == 1 else main
+        if last is not None and last["lane"] != lane and not wait:
+            stream.wait_event(last["done"])        # not an overlapping pair: the whole of the previous step first
+        # (an overlapping pair needs no more: the side stream only ever follows an eligible step on the caller's stream,
+        # and its first per-layer wait also covers everything that stream held before that step)
+        self._step_depth, self._step_fb = 1, fb
+        try:
+            with torch.cuda.stream(stream):
+                yield fb
+                done = torch.cuda.Event()
+                done.record(stream)
+        finally:
+            self._step_depth, self._step_fb = 0, None
+        self._last_step = dict(lane=lane, done=done, record=record)
+        if lane == 1 and join:
+            main.wait_event(done)
+            self._last_step = dict(lane=0, done=done, record=0)                 # as if it had run on the caller's stream
+
     def _forward_rows(self, seqs, want_temps):
         """A step up to the final norm: (hidden, cu_seqlens_q | None, rows to keep | None, row count, temperatures, need).
         cu_seqlens_q None: the rows of `hidden` are the LM head's rows as they are (a graph replay); a row count of 0: no
         sequence finishes its scheduled prompt in this step and nothing is to be projected."""
-        fb = flatten_batch(seqs, self.block_size)
-        fb["fed"] = self._fed_indices(seqs, fb)
-        graph = self._graph_for(fb)
+        fb = self._step_fb
+        assert fb is not None, "_forward_rows runs inside _step()"
+        graph = fb["graph"]
         need_host = torch.from_numpy(fb["need"])
         if graph is not None:
+            if fb["fed"] is not None:
+                self.prev_sampled.record_stream(torch.cuda.current_stream())
             hidden, temps = graph.replay(fb, seqs, want_temps, self.prev_sampled)
             out = (hidden[:len(seqs)], None, None, len(seqs), temps, need_host)
         else:
@@ -537,13 +610,14 @@ class ModelRunner:
         with ``need`` a HOST int32 tensor (indices into ``seqs`` of the rows of ``logits``).  logits is
         None on ranks > 0 and when no sequence finishes its scheduled prompt in this step.  ``gather=False`` (tensor
         parallelism with the native executor): every rank keeps the logits of ITS vocabulary shard, [B', V / tp]."""
-        hidden, cu, keep, n, temps, need_host = self._forward_rows(seqs, self.rank == 0 or not gather)
-        if n == 0:
-            logits = None
-        elif self.native is not None:
-            logits = self.native.logits(hidden, cu, keep, n, gather=gather)
-        else:
-            logits = self.model.lm_head.forward_rows(hidden)
+        with self._step(seqs, join=True):
+            hidden, cu, keep, n, temps, need_host = self._forward_rows(seqs, self.rank == 0 or not gather)
+            if n == 0:
+                logits = None
+            elif self.native is not None:
+                logits = self.native.logits(hidden, cu, keep, n, gather=gather)
+            else:
+                logits = self.model.lm_head.forward_rows(hidden)
         return logits, temps, need_host
 
     @torch.inference_mode()
@@ -552,6 +626,10 @@ class ModelRunner:
         without sampling over the vocabulary shards, on ranks > 0.  Three routes to the same ids: the LM head with
         the sampler in its epilogue (one GPU, batches that take its 256 x 256 tile: the logits are never written),
         sampling over the ranks' shards, or the sampler over the (gathered) logits."""
+        with self._step(seqs, join=True):
+            return self._forward_sampled(seqs)
+
+    def _forward_sampled(self, seqs):
         if self.fused_head and self.native is not None and self.world_size == 1:
             hidden, cu, keep, n, temps, need_host = self._forward_rows(seqs, True)
             if n == 0:
@@ -584,10 +662,11 @@ class ModelRunner:
     @torch.inference_mode()
     def run(self, seqs):
         t0 = time.perf_counter()
-        ids, need_host = self.forward_sampled(seqs)
-        token_ids = None
-        if self.rank == 0:                      # (with shard sampling every rank holds the ids; the contract hands them to rank 0's caller)
-            token_ids = [] if ids is None else ids.tolist()
+        with self._step(seqs):
+            ids, need_host = self.forward_sampled(seqs)
+            token_ids = None
+            if self.rank == 0:                  # (with shard sampling every rank holds the ids; the contract hands them to rank 0's caller)
+                token_ids = [] if ids is None else ids.tolist()
         if self.comm is not None and time.perf_counter() - t0 > 2.0:
             self.comm.check()                   # a step this slow may have sat through an exchange timeout: raise, do not go on
         return token_ids, need_host
@@ -611,25 +690,26 @@ class ModelRunner:
         them with `.result()` when it needs them - normally after it has launched the next step.  Under tensor
         parallelism every rank calls it with the same sequences: rank 0 samples, the ids reach the other ranks on the
         device (comm.broadcast_ids), and every rank can read them back."""
-        sampled, need_host = self.forward_sampled(seqs)
-        need = need_host.tolist()
-        count = len(need) if (need or any(len(s.block_table) for s in seqs)) else len(seqs)
-        if count == 0:
+        with self._step(seqs):
+            sampled, need_host = self.forward_sampled(seqs)
+            need = need_host.tolist()
+            count = len(need) if (need or any(len(s.block_table) for s in seqs)) else len(seqs)
+            if count == 0:
+                event = torch.cuda.Event()
+                event.record()
+                return PendingTokens(None, event, need, 0)
+            if self.world_size > 1 and not self.shard_sampling:
+                sampled = comm.broadcast_ids(sampled, count, self.device)
+            n = sampled.numel()
+            self._token_flip ^= 1
+            buf = self._token_bufs[self._token_flip]
+            if buf is None or buf.numel() < n:
+                buf = self._token_bufs[self._token_flip] = torch.empty(max(n, 1024), dtype=torch.int64, device="cpu", pin_memory=True)
+            buf[:n].copy_(sampled, non_blocking=True)
             event = torch.cuda.Event()
             event.record()
-            return PendingTokens(None, event, need, 0)
-        if self.world_size > 1 and not self.shard_sampling:
-            sampled = comm.broadcast_ids(sampled, count, self.device)
-        n = sampled.numel()
-        self._token_flip ^= 1
-        buf = self._token_bufs[self._token_flip]
-        if buf is None or buf.numel() < n:
-            buf = self._token_bufs[self._token_flip] = torch.empty(max(n, 1024), dtype=torch.int64, device="cpu", pin_memory=True)
-        buf[:n].copy_(sampled, non_blocking=True)
-        event = torch.cuda.Event()
-        event.record()
-        self.prev_sampled = sampled
-        return PendingTokens(buf, event, need, n)
+            self.prev_sampled = sampled
+            return PendingTokens(buf, event, need, n)
 
     # -------------------------------------------------------------- hipGraph decode
     @torch.inference_mode()

@@ -32,7 +32,7 @@ class StepDesc(C.Structure):
                 ("table_stride", i64), ("max_seqlen_q", i32), ("max_seqlen_k", i32), ("mode", i32), ("decode_splits", i32),
                 ("decode_min_range", i32), ("decode_prefix", i64), ("cu_seqlens_q_tail", vp), ("cu_seqlens_k_tail", vp),
                 ("decode_items", i64), ("decode_item_seq", vp), ("decode_item_range", vp), ("decode_seq_active", vp),
-                ("decode_seq_chunk", vp)]
+                ("decode_seq_chunk", vp), ("layer_events_wait", i32), ("layer_events_record", i32)]
 
 
 def _ptr(t):
@@ -106,11 +106,13 @@ class NativeQwen3:
         d.v_cache = arr("vc", [l.self_attn.attn.v_cache for l in layers])
         self.desc = d
         self.device = m.lm_head.weight.device
+        # per-layer events that order two steps in flight on two streams (created once; nothing is created inside a step)
+        self.layer_events = self.comm is None and self.reduce_fn is None and self.lib.nvh_qwen3_prepare_layer_events(d.layers) >= d.layers
 
     def forward(self, input_ids, positions, *, mode, batch, cu_seqlens_q=None, cu_seqlens_k=None, max_seqlen_q=0,
                 max_seqlen_k=0, slot_mapping=None, context_lens=None, block_tables=None, decode_splits=1,
                 decode_prefix=0, cu_seqlens_q_tail=None, cu_seqlens_k_tail=None, decode_min_range=0,
-                decode_items=None, out=None, workspace=None):
+                decode_items=None, layer_events=(0, 0), out=None, workspace=None):
         """One step: final-norm hidden states [T, hidden].  `out` / `workspace` (uint8, at least workspace_bytes()):
         buffers of the caller's instead of fresh ones - a capture that runs two steps side by side on two streams
         allocates them beforehand."""
@@ -131,6 +133,7 @@ class NativeQwen3:
         if decode_prefix:
             st.decode_prefix = decode_prefix
             st.cu_seqlens_q_tail, st.cu_seqlens_k_tail = _ptr(cu_seqlens_q_tail), _ptr(cu_seqlens_k_tail)
+        st.layer_events_wait, st.layer_events_record = layer_events     # two steps in flight (nvh_step.layer_events_wait)
         nbytes = self.lib.nvh_qwen3_workspace_bytes(C.byref(self.desc), t, batch, st.decode_splits)
         ws = workspace if workspace is not None else torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         assert ws.numel() >= nbytes

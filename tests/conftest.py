@@ -17,6 +17,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture
+def switches():
+    """set(name, value) for the library's routing switches (value -1 unsets); everything touched is restored afterwards."""
+    from nanovllm import _hip
+    touched = {}
+
+    def set_switch(name: str, value: int = 1):
+        key = name.encode()
+        if key not in touched:
+            touched[key] = _hip.lib().nvh_get_switch(key)
+            assert touched[key] != -2, f"unknown switch {name}"
+        _hip.call("nvh_set_switch", key, value)
+
+    yield set_switch
+    for key, prev in touched.items():
+        _hip.call("nvh_set_switch", key, prev)
+
+
 def from_bits(a: np.ndarray) -> torch.Tensor:
     """uint16 bit patterns -> bf16 tensor."""
     return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)

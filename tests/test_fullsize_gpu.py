@@ -202,7 +202,7 @@ def test_fused_qkv_epilogue_route_equals_two_launch_route(eager, tokens):
 
 
 @pytest.mark.parametrize("batch", [1, 5, 16, 27])
-def test_decode_prologue_fusion_at_full_size(eager, monkeypatch, batch):
+def test_decode_prologue_fusion_at_full_size(eager, switches, batch):
     """Decode steps of 1..32 sequences at the real shape (rows of 1024: sixteen k-tiles resident per workgroup, 128 and
     96..192 column tiles, two row tiles from 17 rows): the residual add + RMSNorm inside the QKV and gate/up projections
     with K-slabs kept gives the bits of the separate launches; the default route (O / down projections over the waves
@@ -212,12 +212,8 @@ def test_decode_prologue_fusion_at_full_size(eager, monkeypatch, batch):
     forced = torch.randint(0, 10000, (2, batch), generator=g).tolist()
     outs = {}
     for mode in ("default", "slabs", "separate"):
-        monkeypatch.delenv("NVH_DECODE_SLABS", raising=False)
-        monkeypatch.delenv("NVH_NO_NORM_GEMM", raising=False)
-        if mode == "slabs":
-            monkeypatch.setenv("NVH_DECODE_SLABS", "1")
-        if mode == "separate":
-            monkeypatch.setenv("NVH_NO_NORM_GEMM", "1")
+        switches("NVH_DECODE_SLABS", 1 if mode == "slabs" else -1)
+        switches("NVH_NO_NORM_GEMM", 1 if mode == "separate" else -1)
         eager.kv_cache.zero_()
         seqs = [seq(p, 0, len(p), [i]) for i, p in enumerate(ps)]
         eager.forward_logits(seqs)

@@ -388,3 +388,4 @@ def test_decode_work_list_covers_every_key_exactly_once():
         assert (np.diff(first) <= 0).all()                                                      # longest ranges first
     plan = ops.plan_decode_items([100, 1023, 1024, 5000], max_ranges=32, range_keys=512)
     assert plan["seq_active"].tolist() == [1, 1, 2, 9] and plan["seq_chunk"].tolist() == [128, 1024, 512, 576]
+

@@ -219,7 +219,7 @@ def test_native_executor_equals_operator_modules(eager, modules):
 
 
 @pytest.mark.parametrize("batch", [1, 3, 8])
-def test_decode_with_the_norm_inside_the_projection_equals_separate_launches(eager, monkeypatch, batch):
+def test_decode_with_the_norm_inside_the_projection_equals_separate_launches(eager, switches, batch):
     """Decode batches fold the residual add + RMSNorm into the prologue of the projection that consumes it (two launches
     less per layer, the residual alternating between two buffers).  With the previous projection's K-slabs kept
     (NVH_DECODE_SLABS) the step must give the bits of the separate launches (NVH_NO_NORM_GEMM); the default route (no
@@ -230,12 +230,8 @@ def test_decode_with_the_norm_inside_the_projection_equals_separate_launches(eag
     forced = torch.randint(0, 1024, (3, batch), generator=g).tolist()        # the same next tokens on every route
     outs = {}
     for mode in ("default", "slabs", "separate"):
-        monkeypatch.delenv("NVH_DECODE_SLABS", raising=False)
-        monkeypatch.delenv("NVH_NO_NORM_GEMM", raising=False)
-        if mode == "slabs":
-            monkeypatch.setenv("NVH_DECODE_SLABS", "1")
-        if mode == "separate":
-            monkeypatch.setenv("NVH_NO_NORM_GEMM", "1")
+        switches("NVH_DECODE_SLABS", 1 if mode == "slabs" else -1)
+        switches("NVH_NO_NORM_GEMM", 1 if mode == "separate" else -1)
         runner.kv_cache.zero_()
         seqs = [seq(p, 0, len(p), [i]) for i, p in enumerate(prompts)]
         logits, _, _ = runner.forward_logits(seqs)
@@ -457,3 +453,54 @@ def test_graph_is_skipped_when_a_one_token_chunk_needs_no_logits(graphed):
     assert torch.equal(logits.float().cpu().argmax(-1), ref.float().argmax(-1))
     toks, need2 = runner.run(batch)
     assert len(toks) == need2.numel() == 2
+
+
+
+def test_two_steps_in_flight_on_two_streams_give_the_bits_of_one_stream(eager):
+    """Consecutive prefill-sized steps that need no ids from each other alternate between the caller's stream and a side
+    stream, ordered per layer (the later step's QKV projection + KV store of a layer behind the earlier step's attention
+    of that layer).  Same kernels in the same order per step, so the logits and the whole KV cache must come out bit for
+    bit as with every step on one stream: three chunks of one prompt (each reads the keys of the one before), then two
+    unrelated prompts, then a prompt that borrows the pages of the first one's prefix."""
+    runner, oracle = eager
+    g = torch.Generator().manual_seed(123)
+    rnd = lambda n: torch.randint(0, 1024, (n,), generator=g).tolist()       # noqa: E731
+    a, b, c = rnd(900), rnd(400), rnd(300)
+    d = a[:512] + rnd(280)                                                    # shares two pages with `a`
+    lanes = []
+    orig = runner.native.forward
+    runner.native.forward = lambda *x, **k: (lanes.append((k.get("layer_events"), torch.cuda.current_stream() != torch.cuda.default_stream())),
+                                             orig(*x, **k))[1]
+    outs = {}
+    try:
+        for overlap in (False, True):
+            runner.step_overlap = overlap
+            runner._last_step = None
+            runner.kv_cache.zero_()
+            lanes.clear()
+            got = []
+            for cached, new in ((0, 300), (300, 300)):                        # chunk steps: no ids, nothing waits for them
+                toks, need = runner.run([seq(a, cached, new, [0, 1, 2, 3][:(cached + new + 255) // 256])])   # the pages scheduled so far
+                assert toks == [] and need.numel() == 0
+            l, _, _ = runner.forward_logits([seq(a, 600, 300, [0, 1, 2, 3])])
+            got.append(l.cpu())
+            toks, need = runner.run([seq(b[:-1] + [0] * 50, 0, 399, [4, 5])])  # (does not reach the end of its tokens: no ids)
+            assert toks == []
+            l, _, _ = runner.forward_logits([seq(c, 0, 300, [6, 7]), seq(d, 512, 280, [0, 1, 8, 9])])
+            got.append(l.cpu())
+            torch.cuda.synchronize()
+            outs[overlap] = (got, runner.kv_cache.cpu().clone(), list(lanes))
+    finally:
+        runner.native.forward = orig
+        runner.step_overlap = True
+    assert all(ev == (0, 0) and not side for ev, side in outs[False][2])
+    assert [ev for ev, _ in outs[True][2]] == [(0, 1), (1, 2), (2, 1), (1, 2), (2, 1)]
+    assert [side for _, side in outs[True][2]] == [False, True, False, True, False]
+    for x, y in zip(outs[True][0], outs[False][0]):
+        assert torch.equal(x, y)
+    assert torch.equal(outs[True][1], outs[False][1])
+    oracle.kv.zero_()
+    for cached, new in ((0, 300), (300, 300)):
+        oracle.run([M.SeqState(list(a), cached, new, [0, 1, 2, 3][:(cached + new + 255) // 256])])
+    ol, _ = oracle.run([M.SeqState(list(a), 600, 300, [0, 1, 2, 3])])
+    close(outs[True][0][0], ol)

@@ -790,7 +790,7 @@ def test_sample_noise_is_never_zero(ops):
         assert ids.cpu().tolist() == [7] * rows, f"offset {offset}: {(ids.cpu() != 7).sum().item()} rows left the leading column"
 
 
-def test_attn_decode_in_launch_merge_equals_merge_launch(ops):
+def test_attn_decode_in_launch_merge_equals_merge_launch(ops, switches):
     """With NVH_DECODE_MERGE_IN_LAUNCH=1 key ranges are merged by the last workgroup of a (sequence, kv head) to arrive,
     inside the attention launch; it must give the bits of the separate merge launch (the default).  Checked on every launch of a run of
     back-to-back launches with other kernels between them (the hand-off between workgroups has to hold under load and
@@ -809,13 +809,11 @@ def test_attn_decode_in_launch_merge_equals_merge_launch(ops):
         want = ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, num_splits=splits).clone()
         x, w = dev(rnd(256, 1024, seed=1)), dev(rnd(1024, 1024, seed=2, scale=0.05))
         outs = []
-        os.environ["NVH_DECODE_MERGE_IN_LAUNCH"] = "1"
-        try:
-            for it in range(12):
-                outs.append(ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, num_splits=splits))
-                ops.linear(x, w)                                  # other work between the launches
-        finally:
-            os.environ.pop("NVH_DECODE_MERGE_IN_LAUNCH")
+        switches("NVH_DECODE_MERGE_IN_LAUNCH", 1)
+        for it in range(12):
+            outs.append(ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, num_splits=splits))
+            ops.linear(x, w)                                  # other work between the launches
+        switches("NVH_DECODE_MERGE_IN_LAUNCH", -1)
         for it, got in enumerate(outs):
             assert torch.equal(got, want), f"launch {it}: {int((got != want).sum())} elements differ (hq {hq}, hkv {hkv})"
         ref = R.attention_decode(q, kc, vc, torch.tensor(lens_k, dtype=torch.int32), bt, scale)
@@ -824,9 +822,7 @@ def test_attn_decode_in_launch_merge_equals_merge_launch(ops):
         plan = ops.plan_decode_items(lens_k, max_ranges=16, range_keys=256, capacity=b + 64)
         items = ops.upload_decode_items(plan, "cuda")
         want_items = ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, items=items).clone()
-        os.environ["NVH_DECODE_MERGE_IN_LAUNCH"] = "1"
-        try:
-            for it in range(4):
-                assert torch.equal(ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, items=items), want_items)
-        finally:
-            os.environ.pop("NVH_DECODE_MERGE_IN_LAUNCH")
+        switches("NVH_DECODE_MERGE_IN_LAUNCH", 1)
+        for it in range(4):
+            assert torch.equal(ops.attn_decode(dq, dkc, dvc, ctx, dbt, scale, items=items), want_items)
+        switches("NVH_DECODE_MERGE_IN_LAUNCH", -1)

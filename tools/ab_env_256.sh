@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+export NVH_TUNING=1   # the library reads its NVH_* routing switches from the environment only under this
 # B=256 decode step and prefill chunk under environment switches given as arguments ("VAR=value" each; "-" = none), same box.
 for e in "$@" "$@"; do
   if [ "$e" = "-" ]; then line=$(timeout -k 10 200 python bench.py --no-extras --steps 64 --warmup 8); else line=$(env $e timeout -k 10 200 python bench.py --no-extras --steps 64 --warmup 8); fi

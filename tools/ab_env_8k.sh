@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+export NVH_TUNING=1   # the library reads its NVH_* routing switches from the environment only under this
 # 8192-token prompts in 1024-token chunks (bench.py's prefill_8k) under environment switches given as arguments
 # ("VAR=value" each; "-" = none), same box.
 for e in "$@" "$@"; do

@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+export NVH_TUNING=1   # the library reads its NVH_* routing switches from the environment only under this
 # Decode step time at the batches given in BATCHES under key-range settings of the decode attention: each argument is
 # "FULL:TARGET" (NVH_DECODE_FULL_WGS, NVH_DECODE_TARGET_WGS) or "-" for the defaults.  Same box for all of them.
 set -e

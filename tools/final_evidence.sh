@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+export NVH_TUNING=1   # the library reads its NVH_* routing switches from the environment only under this
 # Bench line, profiles (tools/collect_evidence.sh), the Qwen3-14B prefill chunk by kernel and the var-len attention
 # sweep in both grid orders, for the build in the tree; everything under gpurun_out/ev/.  Each GPU step runs under its own
 # time limit; the script stops at the first failure.

@@ -1,4 +1,5 @@
 #!/usr/bin/env bash
+export NVH_TUNING=1   # the library reads its NVH_* routing switches from the environment only under this
 # Decode step time at small batches: add + RMSNorm in the next projection's prologue with K split between waves (fused),
 # the same with split-K slabs (slabs), and the separate launches (unfused).
 set -e
