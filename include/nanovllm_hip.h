@@ -152,6 +152,10 @@ int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const void* w, con
 int64_t nvh_gemm_workspace_bytes(int64_t M, int64_t N, int32_t split_k);
 /* Suggested split (1 = none) for a weight-streaming GEMM of this shape on 256 CUs. */
 int32_t nvh_gemm_suggest_split_k(int64_t M, int64_t N, int64_t K);
+/* Which kernel(s) nvh_gemm_bf16_nt (flavor 0), nvh_gemm_swiglu_bf16_nt (1), nvh_gemm_qkv_rope_store (2; N = (Hq + 2 Hkv) *
+ * 128) or nvh_lm_head_sample (3) would launch for this shape, as text in `out` ("; " between launches), without launching
+ * anything.  The choice is a pure function of the shape (and of the routing switches); tests pin the tuned shapes with it. */
+int32_t nvh_gemm_plan(int64_t M, int64_t N, int64_t K, int32_t split_k, int32_t flavor, char* out, int64_t out_bytes);
 /* y = bf16(sum of slabs (+bias)). */
 int32_t nvh_splitk_reduce(const float* partials, int64_t num_partials, const void* bias,
                           void* y, int64_t y_row_stride, int64_t M, int64_t N, nvh_stream_t stream);

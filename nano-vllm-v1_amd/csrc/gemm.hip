@@ -21,6 +21,8 @@
 // outputs, BM = 16/32/64 for decode batches); split-K (gridDim.z) adds workgroups for narrow-N
 // projections, writing fp32 slabs that the consumer kernel sums.
 #include <stdlib.h>
+#include <stdarg.h>
+#include <string.h>
 #include "common.h"
 
 #define BK 64
@@ -1004,7 +1006,22 @@ struct GemmArgs {
     bool swiglu;
     const QkvEpilogue* qkv = nullptr;   // set: the QKV epilogue (128x128 tiles only)
     const SampleEpilogue* sample = nullptr;   // set: the sampling epilogue (256x256 tiles only)
+    char* plan = nullptr;               // set: launch nothing, append the name of every launch that would be made (nvh_gemm_plan)
+    size_t plan_bytes = 0;
 };
+
+// nvh_gemm_plan: one entry per launch, "; " between them
+void plan_note(const GemmArgs& a, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void plan_note(const GemmArgs& a, const char* fmt, ...) {
+    const size_t used = strlen(a.plan);
+    if (used + 3 >= a.plan_bytes) return;
+    size_t at = used;
+    if (used) { a.plan[at++] = ';'; a.plan[at++] = ' '; a.plan[at] = 0; }
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(a.plan + at, a.plan_bytes - at, fmt, ap);
+    va_end(ap);
+}
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false, bool SAMPLE = false>
 void launch_gemm_nt(const GemmArgs& a) {
@@ -1015,6 +1032,11 @@ void launch_gemm_nt(const GemmArgs& a) {
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
+    }
+    if (a.plan) {
+        plan_note(a, "tile %dx%d waves %dx%d stages %d%s%s%s%s%s grid %ldx%ldx%d", BM, BN, WAVES_N, WAVES_M, STAGES, NT_W ? " nt" : "", SWIGLU ? " swiglu" : "",
+                  QKV ? " qkv" : "", SAMPLE ? " sample" : "", a.partials || a.split_k > 1 ? " slabs" : "", (long)nvh_cdiv(a.N, BN), (long)nvh_cdiv(a.M, BM), a.split_k);
+        return;
     }
     const int ktiles = a.K / BK;
     const bool no_wide = nvh_switch_on(SW_GEMM_NO_WIDE_STORE);   // A/B switch for measurements
@@ -1036,6 +1058,10 @@ void launch_gemm_kgroups(const GemmArgs& a) {
     if (!configured) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
+    }
+    if (a.plan) {
+        plan_note(a, "kgroups 64x64 stages %d grid %ldx%ld", STAGES, (long)nvh_cdiv(a.N, 64), (long)nvh_cdiv(a.M, 64));
+        return;
     }
     dim3 grid((unsigned)nvh_cdiv(a.N, 64), (unsigned)nvh_cdiv(a.M, 64), 1);
     const bool no_xcd = nvh_switch_on(SW_GEMM_NO_XCD);
@@ -1204,6 +1230,10 @@ static bool takes_kwaves(const GemmArgs& a) {
 template <int KW, int COLS>
 static void launch_kwaves(const GemmArgs& a) {
     constexpr int TM = 1;
+    if (a.plan) {
+        plan_note(a, "kwaves %d cols %d grid %ldx%ld", KW, COLS, (long)nvh_cdiv(a.N, COLS), (long)nvh_cdiv(a.M, 16));
+        return;
+    }
     auto kern = gemm_kwaves_bf16_nt_kernel<KW, COLS>;
     static bool configured = false;
     if (!configured) {
@@ -1222,7 +1252,7 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         const bool narrow = !no8 && nvh_cdiv(a.N, 8) * nvh_cdiv(a.M, 16) <= 256;
         if (a.K / BK >= 32) { if (narrow) launch_kwaves<8, 8>(a); else launch_kwaves<8, 16>(a); }
         else { if (narrow) launch_kwaves<4, 8>(a); else launch_kwaves<4, 16>(a); }
-        NVH_CHECK_LAUNCH("gemm_kwaves_bf16_nt");
+        if (!a.plan) NVH_CHECK_LAUNCH("gemm_kwaves_bf16_nt");
         return NVH_OK;
     }
     const int s128 = (int)nvh_switch_or(SW_GEMM_S128, 0);   // tuning switches
@@ -1252,10 +1282,10 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
             return rc != NVH_OK ? rc : dispatch_gemm(tail);
         }
     }
-    if (tile == T128x128 && s128 == 3) { launch_gemm<128, 128, 2, 2, 3>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
-    if (tile == T128x128 && s128 == 4) { launch_gemm<128, 128, 2, 2, 4>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
-    if (tile == T64x64 && s64 == 6) { launch_gemm<64, 64, 2, 2, 6>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
-    if (tile == T64x64 && s64 == 8) { launch_gemm<64, 64, 2, 2, 8>(a); NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    if (tile == T128x128 && s128 == 3) { launch_gemm<128, 128, 2, 2, 3>(a); if (!a.plan) NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    if (tile == T128x128 && s128 == 4) { launch_gemm<128, 128, 2, 2, 4>(a); if (!a.plan) NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    if (tile == T64x64 && s64 == 6) { launch_gemm<64, 64, 2, 2, 6>(a); if (!a.plan) NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
+    if (tile == T64x64 && s64 == 8) { launch_gemm<64, 64, 2, 2, 8>(a); if (!a.plan) NVH_CHECK_LAUNCH("gemm_bf16_nt"); return NVH_OK; }
     switch (tile) {
         case T16x32: {
             // outputs a little wider than one round of 32-column workgroups (768 fit the chip): 64-column tiles put
@@ -1315,8 +1345,34 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T256x128: launch_gemm<256, 128, 2, 2, 3>(a); break;
         case T256x256: launch_gemm<256, 256, 2, 4, 2>(a); break;
     }
-    NVH_CHECK_LAUNCH("gemm_bf16_nt");
+    if (!a.plan) NVH_CHECK_LAUNCH("gemm_bf16_nt");
     return NVH_OK;
+}
+
+// Which kernel(s) dispatch_gemm launches for a shape, without launching: for tests that pin the tuned shapes.
+extern "C" int32_t nvh_gemm_plan(int64_t M, int64_t N, int64_t K, int32_t split_k, int32_t flavor, char* out, int64_t out_bytes) {
+    NVH_REQUIRE(out && out_bytes >= 16, NVH_EINVAL, "nvh_gemm_plan: no room for the answer");
+    NVH_REQUIRE(M >= 1 && M < (1 << 30) && N >= 4 && N < (1 << 30) && K >= BK && K % BK == 0 && split_k >= 1 && split_k <= 64 && K / BK >= split_k &&
+                    flavor >= 0 && flavor <= 3, NVH_EINVAL, "nvh_gemm_plan: shape or flavor out of range");
+    out[0] = 0;
+    static const QkvEpilogue qe{};
+    static const SampleEpilogue se{};
+    GemmArgs a{nullptr, nullptr, nullptr, (bf16*)out, nullptr, K, N, (int)M, (int)N, (int)K, split_k, nullptr, flavor == 1};
+    a.partials = split_k > 1 ? (float*)out : nullptr;     // (never dereferenced: nothing is launched)
+    a.plan = out;
+    a.plan_bytes = (size_t)out_bytes;
+    if (flavor == 2) {
+        // the route nvh_gemm_qkv_rope_store takes: the epilogue inside 128 x 128 tiles of one round, else two launches
+        if (!nvh_switch_on(SW_NO_FUSED_QKV) && pick_tile(M, N, 1) == T128x128 && nvh_cdiv(M, 128) * nvh_cdiv(N, 128) <= 256) a.qkv = &qe;
+    }
+    if (flavor == 3) {
+        NVH_REQUIRE(nvh_lm_head_sample_fused(M, N, K), NVH_ENOSYS, "nvh_gemm_plan: this shape does not take the sampling epilogue");
+        a.sample = &se;
+        a.y = nullptr;
+    }
+    const int32_t rc = dispatch_gemm(a);
+    if (rc == NVH_OK && flavor == 2 && !a.qkv) plan_note(a, "qknorm_rope_store");
+    return rc;
 }
 
 // ------------------------------------------------------------------ split-K slab reduction

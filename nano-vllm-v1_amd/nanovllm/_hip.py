@@ -42,6 +42,7 @@ SIGNATURES = {
     "nvh_gemm_bf16_nt": (i32, [vp, i64, vp, vp, vp, i64, i64, i64, i64, i32, vp, vp]),
     "nvh_gemm_workspace_bytes": (i64, [i64, i64, i32]),
     "nvh_gemm_suggest_split_k": (i32, [i64, i64, i64]),
+    "nvh_gemm_plan": (i32, [i64, i64, i64, i32, i32, C.c_char_p, i64]),
     "nvh_splitk_reduce": (i32, [vp, i64, vp, vp, i64, i64, i64, vp]),
     "nvh_gemm_swiglu_bf16_nt": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, vp]),
     "nvh_interleave_gate_up": (i32, [vp, vp, i64, i64, vp]),
