@@ -1,6 +1,8 @@
 """Engine configuration: the twelve fields (names and defaults) of the reference's config.py:53-64, plus
-``async_scheduling`` (not in the reference; off by default): the engine schedules and launches step n+1 before it has
-read step n's sampled ids, so the GPU never waits for the host between steps.
+``async_scheduling`` (not in the reference; ON by default): the engine schedules and launches step n+1 before it has
+read step n's sampled ids, so the GPU never waits for the host between steps.  Same tokens as the synchronous loop up
+to what depends on WHEN a value is seen (eos ends a sequence one step later: the token computed past it is dropped);
+``async_scheduling=False`` runs the reference's loop (engine/llm_engine.py:117-126): schedule, run, read ids, postprocess.
 
 ``model`` is a local directory holding a Hugging Face ``config.json`` (and optionally
 ``*.safetensors`` weights; without them the runner initialises synthetic weights).
@@ -46,7 +48,7 @@ class Config:
     kvcache_block_size: int = 256
     num_kvcache_blocks: int = -1
     chunked_prefill: bool = False
-    async_scheduling: bool = False
+    async_scheduling: bool = True
 
     def __post_init__(self):
         # the reference asserts a multiple of 256 (config.py:82) but its Sequence.block_size is the constant 256

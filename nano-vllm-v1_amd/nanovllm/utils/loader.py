@@ -40,6 +40,8 @@ def load_tensors(model: nn.Module, named_tensors, loaded: set | None = None) -> 
                     raise KeyError(f"checkpoint tensor {name!r} maps to {pname!r}, which is not a parameter of the model")
                 param = params[pname]
                 param.weight_loader(param, tensor, shard_id)
+                if loaded is not None:
+                    loaded.add((pname, shard_id))              # a packed parameter is complete only with every one of its shards
                 break
         else:
             if name not in params:
@@ -56,6 +58,20 @@ def load_tensors(model: nn.Module, named_tensors, loaded: set | None = None) -> 
 
 def check_all_loaded(model: nn.Module, loaded: set) -> None:
     """Every parameter must have received data; a tied lm_head shares the embedding's storage."""
+    packed = getattr(model, "packed_modules_mapping", {})
+    shards_of = {}                                  # packed target (qkv_proj, gate_up_proj) -> the shard ids that fill it
+    for target, shard_id in packed.values():
+        shards_of.setdefault(target, set()).add(shard_id)
+    incomplete = []
+    for name in sorted(n for n in loaded if isinstance(n, str)):
+        for target, ids in shards_of.items():
+            if f".{target}." in f".{name}" or name.startswith(target + "."):
+                lacking = sorted(str(i) for i in ids if (name, i) not in loaded)
+                if lacking:
+                    incomplete.append(f"{name} (shards {', '.join(lacking)} missing)")
+    if incomplete:
+        raise RuntimeError(f"{len(incomplete)} packed parameters were only partly loaded from the checkpoint: {incomplete[:8]}"
+                           f"{' ...' if len(incomplete) > 8 else ''}")
     seen_ptrs = {p.data_ptr() for name, p in model.named_parameters() if name in loaded}
     missing = [name for name, p in model.named_parameters() if name not in loaded and p.data_ptr() not in seen_ptrs]
     if missing:

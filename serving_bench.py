@@ -111,7 +111,10 @@ def main(argv=None):
     ap.add_argument("--random-output-len", type=int, default=128)
     ap.add_argument("--chunked-prefill", action="store_true")
     ap.add_argument("--enforce-eager", action="store_true")
-    ap.add_argument("--async-scheduling", action="store_true", help="the engine launches step n+1 before it reads step n's ids")
+    ap.add_argument("--async-scheduling", action="store_true", default=True,
+                    help="the engine launches step n+1 before it reads step n's ids (the engine's default)")
+    ap.add_argument("--sync-scheduling", dest="async_scheduling", action="store_false",
+                    help="the reference's loop: schedule, run, read ids back, postprocess")
     ap.add_argument("--num-kvcache-blocks", type=int, default=-1, help="KV pages (default: from free memory)")
     ap.add_argument("--warmup-requests", type=int, default=50)
     args = ap.parse_args(argv)

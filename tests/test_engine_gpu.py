@@ -53,9 +53,13 @@ def prompts_of(lengths, seed):
     return [torch.randint(0, 1024, (n,), generator=g).tolist() for n in lengths]
 
 
-def test_generate_mixed_lengths_chunked(weights):
+BOTH_LOOPS = pytest.mark.parametrize("ahead", [True, False], ids=["one_step_ahead", "synchronous"])   # Config.async_scheduling
+
+
+@BOTH_LOOPS
+def test_generate_mixed_lengths_chunked(weights, ahead):
     from nanovllm import SamplingParams
-    llm = make_llm(weights, max_num_batched_tokens=200)       # forces chunking and mixed prefill+decode steps
+    llm = make_llm(weights, max_num_batched_tokens=200, async_scheduling=ahead)       # forces chunking and mixed prefill+decode steps
     try:
         prompts = prompts_of([5, 300, 257, 64, 700], seed=3)
         sps = [SamplingParams(temperature=1e-9, max_tokens=n, ignore_eos=True) for n in (6, 4, 9, 3, 5)]
@@ -68,9 +72,10 @@ def test_generate_mixed_lengths_chunked(weights):
         llm.exit()
 
 
-def test_generate_prefix_reuse_and_preemption(weights):
+@BOTH_LOOPS
+def test_generate_prefix_reuse_and_preemption(weights, ahead):
     from nanovllm import SamplingParams
-    llm = make_llm(weights, num_kvcache_blocks=4, max_num_batched_tokens=1024)
+    llm = make_llm(weights, num_kvcache_blocks=4, max_num_batched_tokens=1024, async_scheduling=ahead)
     try:
         shared = prompts_of([520], seed=4)[0]
         tails = prompts_of([10, 20, 250], seed=5)
@@ -98,10 +103,11 @@ def test_generate_prefix_reuse_and_preemption(weights):
         llm.exit()
 
 
-def test_step_without_finished_prompt_returns_no_tokens(weights):
+@BOTH_LOOPS
+def test_step_without_finished_prompt_returns_no_tokens(weights, ahead):
     """A lone long prompt under chunked prefill: the first chunks produce no token and must not break the loop."""
     from nanovllm import SamplingParams
-    llm = make_llm(weights, max_num_batched_tokens=128)
+    llm = make_llm(weights, max_num_batched_tokens=128, async_scheduling=ahead)
     try:
         prompt = prompts_of([600], seed=6)[0]
         out = llm.generate([prompt], SamplingParams(temperature=1e-9, max_tokens=3, ignore_eos=True), use_tqdm=False)
@@ -220,7 +226,7 @@ def test_one_step_ahead_engine_ends_at_eos_and_survives_preemption(weights):
     from nanovllm import SamplingParams
     prompts = prompts_of([250, 252, 255, 40, 9], seed=12)
     sp = SamplingParams(temperature=1e-9, max_tokens=40, ignore_eos=True)
-    llm = make_llm(weights, num_kvcache_blocks=4, max_num_batched_tokens=1024)
+    llm = make_llm(weights, num_kvcache_blocks=4, max_num_batched_tokens=1024, async_scheduling=False)
     try:
         free_run = [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
     finally:
@@ -245,4 +251,8 @@ def test_one_step_ahead_engine_ends_at_eos_and_survives_preemption(weights):
     for p, ids, w in zip(prompts, got, want):
         assert -1 not in ids and (eos not in ids[:-1]) and (ids[-1] == eos or len(ids) == 40)
         check_teacher_forced(weights, p, ids)
-    assert sum(g == w for g, w in zip(got, want)) >= len(want) - 1          # at most one bf16 tie resolved the other way
+    # (Not asserted: that `got` repeats the synchronous run id for id.  The two loops see different row counts in some
+    # steps - a finished sequence costs the ahead loop one wasted row - a row count picks the GEMM tile, the tile the order
+    # of a few fp32 sums, and a near-tie of two logits may then resolve the other way.  The invariant is the one checked
+    # above: every id is the oracle's choice at its position, eos ends the sequence, nothing follows it.)
+    assert sum(len(g) < 40 for g in got) >= 1

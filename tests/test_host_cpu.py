@@ -202,6 +202,27 @@ def test_loader_packed_mapping_and_tied_head():
     assert all(torch.equal(tensors[k], again[k]) for k in tensors)
 
 
+def test_loader_refuses_a_checkpoint_that_lacks_one_shard_of_a_packed_parameter():
+    """qkv_proj / gate_up_proj are filled from three / two checkpoint tensors each; a checkpoint without one of them
+    (k_proj of one layer, up_proj of another) must not pass for complete, nor must one without a whole parameter."""
+    from types import SimpleNamespace
+    from nanovllm.models.qwen3 import Qwen3ForCausalLM
+    from nanovllm.utils.loader import check_all_loaded, load_tensors, synthetic_tensors
+    from conftest import TINY
+    hf = SimpleNamespace(**TINY, rms_norm_eps=1e-6, rope_theta=1e6, rope_scaling=None, attention_bias=False,
+                         hidden_act="silu", tie_word_embeddings=True)
+    tensors = dict(synthetic_tensors(hf, seed=3, device="cpu", dtype=torch.float32))
+    loaded = set()
+    load_tensors(Qwen3ForCausalLM(hf), tensors.items(), loaded)
+    check_all_loaded(Qwen3ForCausalLM(hf), loaded)                       # complete: passes
+    for gone, word in (("model.layers.1.self_attn.k_proj.weight", "shards k missing"), ("model.layers.0.mlp.up_proj.weight", "shards 1 missing"),
+                       ("model.layers.0.mlp.down_proj.weight", "not loaded")):
+        model, loaded = Qwen3ForCausalLM(hf), set()
+        load_tensors(model, ((k, v) for k, v in tensors.items() if k != gone), loaded)
+        with pytest.raises(RuntimeError, match=word):
+            check_all_loaded(model, loaded)
+
+
 # ------------------------------------------------------------------ world_size-2 over gloo
 def _tp_worker(rank, ws, port, q):
     """Tensor-parallel layer algebra on CPU: the GEMM / embedding kernels are replaced BY THE TEST with
@@ -248,7 +269,10 @@ def test_tensor_parallel_layers_world2_gloo():
     from oracle import ref_ops as R
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os_getpid() % 500)
+    import socket
+    with socket.socket() as sock:                      # a port nobody holds right now (a pid-derived one collided now and then)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

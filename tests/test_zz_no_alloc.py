@@ -48,10 +48,22 @@ def _both(hip, q, kc, vc, ctx, bt, splits, min_range):
     hip.call("nvh_attn_decode", *common, ref.data_ptr(), splits, min_range, ws.data_ptr(), st)
     got = torch.full((b, hq, d), float("nan"), dtype=BF, device="cuda")
     torch.cuda.synchronize()
+    # Two witnesses that the call allocates nothing: the device's own count of free bytes (hipMemGetInfo sees hipMalloc,
+    # hipMallocAsync and pool growth by anyone in the process, not just torch's caching allocator) does not move, and the
+    # call is accepted under stream capture, where an allocation or a synchronisation fails the capture.
+    free_before = torch.cuda.mem_get_info()[0]
     before = torch.cuda.memory_allocated()
     hip.call("nvh_attn_decode_noalloc", *common, got.data_ptr(), splits, min_range, st)
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before
+    captured = torch.full((b, hq, d), float("nan"), dtype=BF, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        hip.call("nvh_attn_decode_noalloc", *common, captured.data_ptr(), splits, min_range, torch.cuda.current_stream().cuda_stream)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, got), "the captured call replays other bits than the direct one"
     return ref.cpu(), got.cpu()
 
 
