@@ -67,7 +67,9 @@ struct SampleEpilogue {
     const float* temps;
     ValIdx* cand;
     uint64_t seed, offset;
-    int64_t col_offset;       // first column of this (shard of the) vocabulary in the full row
+    int64_t col_offset;       // first column of this launch's columns in the full row (shard of the vocabulary, column cut)
+    int cand_stride;          // candidates per row in `cand` (all launches of a call together)
+    int cand_base;            // this launch's first slot in a row's candidates
 };
 
 // Tile of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id.  With xcd_strip = 8 or 4 (host: gridDim.x a
@@ -281,8 +283,11 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
 
     // epilogue: lane holds n = n_base + fq*4 .. +3 of row m = m_base + fr
     if constexpr (SAMPLE) {
-        static_assert(NW == 8 && !SWIGLU && !QKV, "sampling epilogue: the eight-wave tile");
-        ValIdx (*sm_cand)[TM][16] = reinterpret_cast<ValIdx (*)[TM][16]>(smem);     // the stages are free: every read of them was waited for before the last barrier
+        static_assert((NW == 8 || NW == 4) && WAVES_N == 2 && !SWIGLU && !QKV, "sampling epilogue: two column halves per workgroup");
+        // the stages are free: in the eight-wave loop every read of them was waited for before its last barrier; the
+        // four-wave loop ends without one
+        if constexpr (NW != 8) __syncthreads();
+        ValIdx (*sm_cand)[TM][16] = reinterpret_cast<ValIdx (*)[TM][16]>(smem);
         ValIdx best[TM];
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int m = m0 + wm * WM + j * 16 + fr;
-                if (m < M) se.cand[(int64_t)m * gridDim.x + bx] = better(best[j], sm_cand[wm][j][fr]);
+                if (m < M) se.cand[(int64_t)m * se.cand_stride + se.cand_base + bx] = better(best[j], sm_cand[wm][j][fr]);
             }
         }
         return;
@@ -1080,7 +1085,7 @@ void launch_gemm(const GemmArgs& a) {
             return;
         }
     }
-    if constexpr (BM == 256 && BN == 256) {
+    if constexpr ((BM == 256 && BN == 256) || (BM == 128 && BN == 128 && WAVES_N == 2 && WAVES_M == 2 && STAGES == 2)) {
         if (a.sample) {
             launch_gemm_nt<BM, BN, WAVES_N, WAVES_M, STAGES, false, false, false, true>(a);
             return;
@@ -1258,7 +1263,12 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
     const int s128 = (int)nvh_switch_or(SW_GEMM_S128, 0);   // tuning switches
     const int s64 = (int)nvh_switch_or(SW_GEMM_S64, 0);
     const Tile tile = pick_tile(a.M, a.N, a.split_k);
-    if (tile == T256x256 && a.split_k == 1 && !a.sample && !a.qkv) {
+    if (a.sample && a.sample->cand_base > 0) {            // the left-over columns of a cut LM head (below): 128 x 128 tiles
+        launch_gemm<128, 128, 2, 2, 2>(a);
+        if (!a.plan) NVH_CHECK_LAUNCH("gemm_bf16_nt");
+        return NVH_OK;
+    }
+    if (tile == T256x256 && a.split_k == 1 && !a.qkv) {
         // One 256 x 256 workgroup fits a CU, so the grid runs in rounds of 256 tiles and a last round with few tiles
         // costs a whole round (Qwen3-14B gate/up at 1024 rows: 544 tiles, 403 us; 512 tiles 300 us).  Columns that make
         // whole rounds go first; a remainder of at most half a round follows as a launch of its own on the tile that
@@ -1270,14 +1280,24 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         const int64_t cols_per_round = 256 / g;                                      // column tiles that complete whole rounds
         const int64_t main_tn = tn / cols_per_round * cols_per_round;
         const int64_t rest = (tn - main_tn) * tm;
-        if (!no_cut && main_tn > 0 && rest > 0 && rest <= 128) {
+        if (!no_cut && main_tn > 0 && rest > 0 && rest <= 128 && !(a.sample && nvh_switch_on(SW_LM_HEAD_NO_CUT))) {
             GemmArgs head = a, tail = a;
             const int64_t n_head = main_tn * 256;
             head.N = (int)n_head;
             tail.N = a.N - (int)n_head;
             tail.w = a.w + n_head * a.K;
-            tail.y = a.y + (a.swiglu ? n_head / 2 : n_head);
             if (a.bias) tail.bias = a.bias + n_head;
+            SampleEpilogue se_tail;
+            if (a.sample) {
+                // the sampling epilogue: the left-over columns leave their candidates (one per 128 columns) in the slots
+                // behind the whole rounds' (one per 256 columns); the pick runs over all of them
+                se_tail = *a.sample;
+                se_tail.col_offset += n_head;
+                se_tail.cand_base = (int)main_tn;
+                tail.sample = &se_tail;
+            } else {
+                tail.y = a.y + (a.swiglu ? n_head / 2 : n_head);
+            }
             const int32_t rc = dispatch_gemm(head);
             return rc != NVH_OK ? rc : dispatch_gemm(tail);
         }
@@ -1522,7 +1542,16 @@ extern "C" int32_t nvh_add_rmsnorm_gemm_bf16_nt(const void* prev, const float* s
 extern "C" int32_t nvh_lm_head_sample_fused(int64_t M, int64_t N, int64_t K) {
     return M > 0 && M <= 65535 && N > 0 && N % 4 == 0 && N + 0 < (1 << 30) && K > 0 && K % BK == 0 && pick_tile(M, N, 1) == T256x256;
 }
-extern "C" int64_t nvh_lm_head_sample_workspace_bytes(int64_t M, int64_t N) { return M * nvh_cdiv(N, 256) * (int64_t)sizeof(ValIdx); }
+// Candidates per row: one per 256 columns of the whole rounds + one per 128 columns of a left-over launch (dispatch_gemm).
+static int64_t lm_head_sample_slots(int64_t M, int64_t N) {
+    const int64_t tm = nvh_cdiv(M, 256), tn = nvh_cdiv(N, 256);
+    int64_t g = tm, r = 256;
+    while (r) { const int64_t t = g % r; g = r; r = t; }
+    const int64_t cols_per_round = 256 / g, main_tn = tn / cols_per_round * cols_per_round, rest = (tn - main_tn) * tm;
+    if (nvh_switch_on(SW_GEMM_NO_ROUND_CUT) || nvh_switch_on(SW_LM_HEAD_NO_CUT) || main_tn == 0 || rest == 0 || rest > 128) return tn;
+    return main_tn + nvh_cdiv(N - main_tn * 256, 128);
+}
+extern "C" int64_t nvh_lm_head_sample_workspace_bytes(int64_t M, int64_t N) { return M * nvh_cdiv(N, 128) * (int64_t)sizeof(ValIdx); }
 
 extern "C" int32_t nvh_lm_head_sample(const void* x, int64_t x_row_stride, const void* w, const float* temperatures, int64_t* out,
                                       int64_t M, int64_t N, int64_t K, uint64_t seed, uint64_t offset, void* workspace,
@@ -1532,12 +1561,13 @@ extern "C" int32_t nvh_lm_head_sample(const void* x, int64_t x_row_stride, const
     NVH_REQUIRE(nvh_lm_head_sample_fused(M, N, K), NVH_ENOSYS,
                 "nvh_lm_head_sample: %ld x %ld x %ld does not take the 256 x 256 tile (ask nvh_lm_head_sample_fused; use nvh_gemm_bf16_nt + nvh_sample)",
                 (long)M, (long)N, (long)K);
-    SampleEpilogue se{temperatures, (ValIdx*)workspace, seed, offset, 0};
+    const int slots = (int)lm_head_sample_slots(M, N);
+    SampleEpilogue se{temperatures, (ValIdx*)workspace, seed, offset, 0, slots, 0};
     GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, nullptr, nullptr, x_row_stride, 0, (int)M, (int)N, (int)K, 1, (hipStream_t)stream, false};
     a.sample = &se;
     const int32_t rc = dispatch_gemm(a);
     if (rc != NVH_OK) return rc;
-    return nvh_launch_sample_final(workspace, out, M, (int)nvh_cdiv(N, 256), (hipStream_t)stream);
+    return nvh_launch_sample_final(workspace, out, M, slots, (hipStream_t)stream);
 }
 
 // dst rows <- src rows of a merged [gate (I rows) | up (I rows)] weight in the interleaved order above.
