@@ -17,6 +17,7 @@ Same contract as the reference's engine/model_runner.py:49-715 -
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import os
 import sys
@@ -143,10 +144,14 @@ class PendingTokens:
         self.buf, self.event, self.need, self.count = buf, event, need, count
 
     def result(self) -> list[int]:
-        """Waits for the step (also one that sampled nothing: the caller never runs more than a step ahead of the GPU)."""
+        """The step's ids, waiting for them.  A step that sampled nothing (a chunk that does not end its prompt) has nothing
+        to wait for: how far the host may run ahead of the GPU over such steps is bounded where steps are launched
+        (ModelRunner._step: LANES steps)."""
+        if not self.count:
+            return []
         if self.event is not None:
             self.event.synchronize()
-        return self.buf[:self.count].tolist() if self.count else []
+        return self.buf[:self.count].tolist()
 
 
 class ModelRunner:
@@ -185,8 +190,10 @@ class ModelRunner:
         # alternate between the caller's stream and a side stream (Qwen3-0.6B: a 1024-token chunk 2.77 -> 2.18 ms; the
         # Qwen3-14B shape 27.7 -> 26.4 ms).  NANOVLLM_STEP_OVERLAP=0 turns it off.
         self.step_overlap = self.world_size == 1 and os.environ.get("NANOVLLM_STEP_OVERLAP", "1") != "0"
-        self._side_stream = None                # created with the first step that takes it
+        self._side_streams = []                 # created with the first steps that take them
         self._last_step = None                  # lane, completion event and event set of the step launched last
+        self._lane_done = {}                    # side lane -> completion event of the last step launched on it
+        self._recent_steps = collections.deque()   # completion events of the steps launched last (bounds the run-ahead)
         self._step_depth, self._step_fb = 0, None
         self.comm = None
         if self.world_size > 1:
@@ -513,24 +520,27 @@ class ModelRunner:
             return None
         return graph
 
-    OVERLAP_MIN_TOKENS = 256     # steps with fewer new tokens are not worth a second stream
+    OVERLAP_MIN_TOKENS = 256     # steps with fewer new tokens are not worth another stream
+    LANES = 4                    # streams that consecutive prefill-sized steps rotate over (the caller's + three side streams)
 
     @contextlib.contextmanager
     def _step(self, seqs, join: bool = False):
         """Everything a step enqueues happens inside this context: it flattens the batch, picks the stream the step runs
-        on and orders it against the step launched before it.
+        on and orders it against the steps launched before it.
 
         Normally that is the caller's stream and stream order.  But a prefill-sized step (a chunk of a prompt, a wave of
-        new prompts) of a small model is ~200 dependent launches that cannot fill the chip one at a time, and the next
-        such step is often launched while it is still running (chunk steps return no ids, so not even the synchronous
-        loop waits for them; the loop that runs one step ahead never does).  Two such steps in a row - eager native
-        steps of one rank that take no token from the sampler output of a step still in flight - therefore alternate
-        between the caller's stream and a side stream and fill each other's idle time.  What orders them is per layer:
-        the later step's QKV projection + KV store of layer l waits for the earlier step's attention of layer l
+        new prompts) is ~200 dependent launches that cannot fill the chip one at a time, and the next such step is often
+        launched while it is still running (chunk steps return no ids, so no loop waits for them; the loop that runs
+        one step ahead never waits before it has launched the next step).  Such steps in a row - eager native steps of one
+        rank that take no token from the sampler output of a step still in flight - therefore rotate over LANES streams
+        (the caller's first) and fill each other's idle time.  What orders two consecutive ones is per layer: the later
+        step's QKV projection + KV store of layer l waits for the earlier step's attention of layer l
         (nvh_step.layer_events_wait), which covers keys the later step reads (the next chunk of the same prompt, shared
-        prefix pages) and pages the earlier step still reads and the later one overwrites.  Every other pair of steps
-        is ordered as a whole.  `join`: the caller's stream also waits for this step (for entry points that hand device
-        tensors back to their caller)."""
+        prefix pages) and pages the earlier step still reads and the later one overwrites; the chain of these waits
+        orders it against the steps before that one, and stream order against the step LANES back.  Any other step runs
+        on the caller's stream behind everything launched before it.  At most LANES steps are ever enqueued ahead of the
+        GPU.  `join`: the caller's stream also waits for this step (for entry points that hand device tensors back to
+        their caller)."""
         if self._step_depth:                        # nested (run -> forward_sampled): the outer context owns the step
             self._step_depth += 1
             try:
@@ -538,6 +548,8 @@ class ModelRunner:
             finally:
                 self._step_depth -= 1
             return
+        while len(self._recent_steps) >= self.LANES:
+            self._recent_steps.popleft().synchronize()
         fb = flatten_batch(seqs, self.block_size)
         fb["fed"] = self._fed_indices(seqs, fb)
         fb["graph"] = self._graph_for(fb)
@@ -549,16 +561,17 @@ class ModelRunner:
         if eligible:
             record = 1
             if last is not None and last["record"]:
-                lane, wait, record = 1 - last["lane"], last["record"], 3 - last["record"]
+                lane, wait, record = (last["lane"] + 1) % self.LANES, last["record"], 3 - last["record"]
         fb["layer_events"] = (wait, record)
         main = torch.cuda.current_stream()
-        if lane == 1 and self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        stream = self._side_stream if lane == 1 else main
-        if last is not None and last["lane"] != lane and not wait:
-            stream.wait_event(last["done"])        # not an overlapping pair: the whole of the previous step first
-        # (an overlapping pair needs no more: the side stream only ever follows an eligible step on the caller's stream,
-        # and its first per-layer wait also covers everything that stream held before that step)
+        while lane > len(self._side_streams):
+            self._side_streams.append(torch.cuda.Stream(device=self.device))
+        stream = self._side_streams[lane - 1] if lane else main
+        if not wait:
+            # not the next of a run of overlapping steps (then lane 0): the whole of everything on the side streams first
+            for ev in self._lane_done.values():
+                main.wait_event(ev)
+            self._lane_done.clear()
         self._step_depth, self._step_fb = 1, fb
         try:
             with torch.cuda.stream(stream):
@@ -568,9 +581,11 @@ class ModelRunner:
         finally:
             self._step_depth, self._step_fb = 0, None
         self._last_step = dict(lane=lane, done=done, record=record)
-        if lane == 1 and join:
-            main.wait_event(done)
-            self._last_step = dict(lane=0, done=done, record=0)                 # as if it had run on the caller's stream
+        self._recent_steps.append(done)
+        if lane:
+            self._lane_done[lane] = done
+            if join:
+                main.wait_event(done)
 
     def _forward_rows(self, seqs, want_temps):
         """A step up to the final norm: (hidden, cu_seqlens_q | None, rows to keep | None, row count, temperatures, need).
