@@ -312,10 +312,12 @@ def kernel_roofline(runner, seqs, iters):
     # HBM bytes per launch from the PMC pass committed under profiles/ (FETCH_SIZE, own rocprofv3 run,
     # doubled as gfx950 requires), scaled from that run's context length to this one's.
     traffic, traffic_note = None, None
-    pmc = ROOT / "profiles" / "r01_attn_decode_traffic.json"
+    pmc = ROOT / "profiles" / "r03_attn_decode_traffic.json"
+    if not pmc.exists():
+        pmc = ROOT / "profiles" / "r01_attn_decode_traffic.json"
     if pmc.exists() and tp == 1 and b == 256:
         rec = json.loads(pmc.read_text())
-        ratio = rec["traffic_bytes_per_launch"] / rec["algorithmic_bytes_per_launch_at_ctx1027"]
+        ratio = rec["traffic_bytes_per_launch"] / rec.get("algorithmic_bytes_per_launch", rec.get("algorithmic_bytes_per_launch_at_ctx1027"))
         traffic = int(bytes_per_launch * ratio)
         traffic_note = f"profiles/{pmc.name}: measured/algorithmic = {ratio:.4f}"
     g = hq // hkv
@@ -378,10 +380,12 @@ def prefill_kernel_roofline(hf, tokens=1024, iters=3):
         total_us += us
         out[name] = dict(us=round(us, 2), tflops=round(flops / us / 1e6, 1), frac=round(flops / us / 1e6 / MFMA_PEAK_TFLOPS, 4))
     dominant = max(out, key=lambda k: out[k]["us"])
-    pmc = ROOT / "profiles" / "r02_prefill_mfma_pmc.txt"
+    # matrix-pipe busy fraction of the kernels of a chunk as the step launches them (counter pass, tools/evidence_json.py)
+    pmc = ROOT / "profiles" / "r03_prefill_mfma_busy.json"
+    busy = {k: v["mfma_busy_frac"] for k, v in json.loads(pmc.read_text()).items()} if pmc.exists() else None
     return dict(bound="mfma", kernel=dominant, achieved=out[dominant]["tflops"], peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                 frac=out[dominant]["frac"], per_kernel=out, per_layer_us=round(total_us, 1),
-                mfma_busy_source=(f"profiles/{pmc.name}" if pmc.exists() else None),
+                mfma_busy_by_step_kernel=busy, mfma_busy_source=(f"profiles/{pmc.name}" if pmc.exists() else None),
                 note="HIP-event time per launch over 12 back-to-back launches replayed from a hipGraph (rotating cold weights); one layer = these five + two add/RMSNorm launches")
 
 
@@ -502,8 +506,8 @@ def main():
         return [torch.randint(0, 10000, (length,), generator=g).tolist() for _ in range(n)]
 
     # ---- prefill of the decode batch: B prompts x context tokens, one 1024-token chunk per step
-    # The loop that runs one step ahead of its sampled ids (what Config.async_scheduling does in the engine): the fastest
-    # way this runner serves; the synchronous loop of the reference is timed next to it for the decode steps.  With
+    # The loop that runs one step ahead of its sampled ids (Config.async_scheduling, the engine's default): what a plain
+    # LLM(model) does; the synchronous loop of the reference is timed next to it for the decode steps.  With
     # several ranks every rank runs the same schedule and the ids reach all of them on the device (comm.broadcast_ids).
     ahead = os.environ.get("NANOVLLM_BENCH_SYNC", "0") != "1"
     seqs = [driver.new_seq(p) for p in prompts(b, ctx0)]
@@ -518,8 +522,11 @@ def main():
                        chunk_tokens=int(chunk_tokens), chunks_timed=len(steady),
                        roofline=dict(bound="mfma", achieved=round(chunk_flops / chunk_s / 1e12, 2), peak=MFMA_PEAK_TFLOPS,
                                      unit="TFLOP/s", frac=round(chunk_flops / chunk_s / 1e12 / MFMA_PEAK_TFLOPS, 4)),
+                       steps_in_flight=2 if (ahead and runner.step_overlap) else 1,
                        note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included"
-                            + (" (engine one step ahead: a chunk's time is the interval between consecutive completions)" if ahead else ""))
+                            + (" (engine one step ahead: a chunk's time is the interval between consecutive completions"
+                               + ("; the chunk launched ahead runs on another stream, ordered against its predecessor per layer" if runner.step_overlap else "")
+                               + ")" if ahead else ""))
     else:
         prefill = dict(note="fewer than two chunks in the prefill of this batch: not timed")
 
@@ -537,7 +544,7 @@ def main():
                config=dict(workload=f"{model_name} TP={world} bf16 decode, B={b} sequences x ~{ctx0} context tokens, "
                                     "chunked_prefill on, max_num_batched_tokens=1024, hipGraph decode",
                            batch=b, context=ctx0, parallelism=f"tp{world}", kv_page=PAGE,
-                           engine_loop=("one step ahead (ModelRunner.run_async, as Config.async_scheduling uses it): step n+1 is launched before step n's ids are read back"
+                           engine_loop=("one step ahead (ModelRunner.run_async; Config.async_scheduling, the engine's default): step n+1 is launched before step n's ids are read back"
                                         if ahead else "synchronous (schedule, run, read ids back, postprocess)")),
                step_roofline=dict(bound="hbm", achieved=round(step_gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(step_gbs / HBM_PEAK_GBS, 4), bytes_per_step=int(step_bytes),

@@ -31,6 +31,11 @@ cd "$R"
 } > "$O/prefill_14b_xcd_order.txt"
 timeout -k 10 200 python3 -u tools/prefill_two_streams_probe.py 1024 8 2 2> /dev/null | tail -1 > "$O/prefill_two_streams.txt"
 timeout -k 10 200 python3 -u tools/prefill_two_streams_probe.py 1024 8 4 2> /dev/null | tail -1 >> "$O/prefill_two_streams.txt"
-timeout -k 10 300 python3 -u serving_bench.py --num-requests 2048 --request-rate 2000 --random-input-len 128 --random-output-len 100 --max-num-batched-tokens 1024 --chunked-prefill --max-model-len 4096 --async-scheduling > "$O/serving_rate2000_async.txt" 2> /dev/null
-timeout -k 10 300 python3 -u serving_bench.py --num-requests 512 --request-rate 100 --random-input-len 128 --random-output-len 100 --max-num-batched-tokens 1024 --chunked-prefill --max-model-len 4096 --async-scheduling > "$O/serving_rate100_async.txt" 2> /dev/null
+timeout -k 10 300 python3 -u serving_bench.py --num-requests 2048 --request-rate 2000 --random-input-len 128 --random-output-len 100 --max-num-batched-tokens 1024 --chunked-prefill --max-model-len 4096 > "$O/serving_rate2000_async.txt" 2> /dev/null
+timeout -k 10 300 python3 -u serving_bench.py --num-requests 512 --request-rate 100 --random-input-len 128 --random-output-len 100 --max-num-batched-tokens 1024 --chunked-prefill --max-model-len 4096 > "$O/serving_rate100_async.txt" 2> /dev/null
+# the reference's offline workload (its bench.py) through LLM.generate, both model shapes, and the steps-in-flight A/B
+timeout -k 10 400 python3 -u tools/offline_bench.py --model qwen3-0.6b 2> /dev/null | tail -2 > "$O/offline_0.6b.txt"
+timeout -k 10 400 python3 -u tools/offline_bench.py --model qwen3-0.6b --sync-scheduling 2> /dev/null | tail -2 > "$O/offline_0.6b_sync.txt"
+timeout -k 10 900 python3 -u tools/offline_bench.py --model qwen3-14b 2> /dev/null | tail -2 > "$O/offline_14b.txt"
+bash tools/ab_overlap.sh > "$O/steps_in_flight_ab.txt" 2>&1
 ls "$O"
