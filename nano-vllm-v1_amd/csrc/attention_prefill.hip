@@ -576,13 +576,6 @@ int key_groups(int g, int64_t wgs, int64_t total_q, int64_t max_seqlen_k) {
 }
 }  // namespace
 
-// Launches that take attn_pair_kernel (a wave = 32 query rows of BOTH heads of a GQA pair, 128-row query blocks): two
-// query heads per kv head, prefill-sized query blocks, and key ranges long enough that the tile loop - not the
-// launch's fixed part - is where the time goes.
-static bool takes_pair(int64_t g, int64_t total_q, int64_t batch, int64_t keys_per_range) {
-    return g == 2 && !nvh_switch_on(SW_ATTN_NO_PAIR) && total_q >= 256 * batch && keys_per_range >= 1024;
-}
-
 extern "C" int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch, int64_t num_q_heads, int64_t num_kv_heads,
                                                   int64_t max_seqlen_k) {
     // Key ranges cost partial results (fp32 O per query row, head and range, written and read back), so a chunk with
@@ -594,16 +587,6 @@ extern "C" int32_t nvh_attn_varlen_suggest_splits(int64_t total_q, int64_t batch
     const int64_t blocks = (total_q / bq + batch) * num_kv_heads;
     const int64_t tiles = nvh_cdiv(max_seqlen_k, 64);
     int64_t s, cap;
-    if (takes_pair(num_q_heads / num_kv_heads, total_q, batch, max_seqlen_k >= 2048 ? 1024 : 0)) {
-        // 128-row query blocks, one workgroup per CU: the range count that brings the grid nearest to one round, every
-        // range at least 1024 keys
-        const int64_t wgs = nvh_cdiv(total_q, 128) * num_kv_heads;       // (sequences of similar length: chunks of prompts)
-        s = (256 + wgs / 2) / (wgs > 0 ? wgs : 1);
-        cap = tiles / 16;
-        if (s > cap) s = cap;
-        if (s > 8) s = 8;
-        return (int32_t)(s < 1 ? 1 : s);
-    }
     if (total_q <= 256) {
         s = nvh_cdiv(512, blocks > 0 ? blocks : 1);
         cap = tiles / 4;
@@ -659,18 +642,6 @@ extern "C" int32_t nvh_attn_varlen(const void* q, int64_t q_token_stride, const 
     const int force_hm = (int)nvh_switch(SW_ATTN_HEAD_MAJOR);
     a.head_major = force_hm >= 0 ? force_hm : (num_splits == 1 || max_seqlen_k >= 6144);
     if (nvh_cdiv(max_seqlen_q, 32) > 65535) a.head_major = 0;          // the query blocks would not fit gridDim.y
-    if (takes_pair(g, total_q, batch, nvh_cdiv(nvh_cdiv(tiles, num_splits) * 64, 1)) && max_seqlen_k >= 2048) {
-        const int tps = (int)nvh_cdiv(tiles, num_splits);
-        dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 128), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));
-        if (a.head_major) grid = dim3(grid.y, grid.x, grid.z);
-        const int stages = (int)nvh_switch_or(SW_ATTN_PAIR_STAGES, 2);
-        const int32_t rc = nvh_launch_attn_pair(paged, stages == 4 ? 4 : 2, grid, st, q, q_token_stride, k, v, kv_token_stride, cu_seqlens_q, cu_seqlens_k,
-                                                block_tables, table_stride, (int)num_kv_heads, softmax_scale * LOG2E, out, num_splits, tps, ws_acc, ws_ml,
-                                                a.head_major);
-        if (rc != NVH_OK) return rc;
-        if (num_splits > 1) return nvh_launch_attn_combine(ws_acc, ws_ml, out, total_q * num_q_heads, num_splits, nullptr, 1, 64, nullptr, st);
-        return NVH_OK;
-    }
 #define LAUNCH_VL(GG, RBB, KSS, STG)                                                                                        \
     do {                                                                                                                    \
         dim3 grid((unsigned)nvh_cdiv(max_seqlen_q, 32 * RBB), (unsigned)num_kv_heads, (unsigned)(batch * num_splits));      \

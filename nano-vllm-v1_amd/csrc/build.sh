@@ -7,13 +7,9 @@ mkdir -p "$out" "$here/.obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 pids=()
-for f in api elementwise attention_decode attention_prefill attention_prefill_pair gemm sampler comm model_forward; do
+for f in api elementwise attention_decode attention_prefill gemm sampler comm model_forward; do
     if [ ! -f "$here/.obj/$f.o" ] || [ "$here/$f.hip" -nt "$here/.obj/$f.o" ] || [ "$here/common.h" -nt "$here/.obj/$f.o" ] || [ "$here/../../include/nanovllm_hip.h" -nt "$here/.obj/$f.o" ]; then
-        extra=""
-        # attention_prefill_pair lays out the accumulator registers by hand (literal a[..] names in its asm): the compiler
-        # must not park spilled VGPRs there
-        [ "$f" = attention_prefill_pair ] && extra="-mllvm -amdgpu-spill-vgpr-to-agpr=0"
-        $HIPCC $FLAGS $extra -c "$here/$f.hip" -o "$here/.obj/$f.o" &
+        $HIPCC $FLAGS -c "$here/$f.hip" -o "$here/.obj/$f.o" &
         pids+=($!)
     fi
 done

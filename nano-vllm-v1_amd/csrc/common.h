@@ -42,11 +42,6 @@ void nvh_set_error(const char* fmt, ...);
 int32_t nvh_launch_attn_combine(const float* ws_acc, const float* ws_ml, void* out, int64_t rows, int num_splits,
                                 const int32_t* ctx_lens, int hq, int min_range, const int32_t* seq_active, hipStream_t st);
 
-// attn_pair_kernel (attention_prefill_pair.hip): long key ranges, two query heads per kv head.
-int32_t nvh_launch_attn_pair(bool paged, int stages, dim3 grid, hipStream_t st, const void* q, int64_t qs, const void* k, const void* v,
-                             int64_t kvs, const int32_t* cu_q, const int32_t* cu_k, const int32_t* tables, int64_t ts, int hkv, float sl2,
-                             void* out, int num_splits, int tiles_per_split, float* ws_acc, float* ws_ml, int head_major);
-
 // Device address, on the current GPU, of the built-in partial-result array of nvh_attn_decode_noalloc (resolved on
 // first use; nvh_device_check resolves it ahead of time for callers that will run under graph capture).
 int32_t nvh_noalloc_scratch(float** out);
@@ -66,7 +61,7 @@ int32_t nvh_decode_arrivals(unsigned** out);
     X(KWAVES_NO_8) X(GEMM_S128) X(GEMM_S64) X(GEMM_NO_ROUND_CUT) X(GEMM_NO_16x64) X(GEMM_NO_KGROUPS)               \
     X(QKV_NO_8WAVE) X(SWIGLU_NO_192) X(SWIGLU_NO_96) X(NO_FUSED_QKV) X(NO_NORM_GEMM) X(NORM_GEMM_KB)               \
     X(NORM_GEMM_ROWS) X(DECODE_SLABS) X(NO_FUSED_EXCHANGE) X(NO_FUSED_DECODE)        \
-    X(LM_HEAD_NO_CUT) X(ATTN_NO_PAIR) X(ATTN_PAIR_STAGES) X(EXP_A) X(EXP_B)
+    X(LM_HEAD_NO_CUT) X(EXP_A) X(EXP_B)
 enum NvhSwitch : int {
 #define NVH_SW_ENUM(n) SW_##n,
     NVH_SWITCHES(NVH_SW_ENUM)
