@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-kernel totals of the LAST complete step in a rocprofv3 kernel trace; a step starts at each launch of the
-delimiter kernel.  usage: trace_breakdown.py <kernel_trace.csv> [delimiter=embedding_kernel] [min_kernels=50]"""
+"""Per-kernel totals of one step in a rocprofv3 kernel trace; a step starts at each launch of the delimiter kernel.
+By default the second to last step (the last may be cut short by the end of the trace); `which` picks another (-1 = last).
+usage: trace_breakdown.py <kernel_trace.csv> [delimiter=embedding_kernel] [min_kernels=50] [which=-2]"""
 import collections
 import csv
 import re
@@ -12,7 +13,8 @@ min_k = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if delim in r["Kernel_Name"]] + [len(rows)]
 spans = [(a, b) for a, b in zip(idx, idx[1:]) if b - a >= min_k]
-a, b = spans[-2] if len(spans) > 1 else spans[-1]
+which = int(sys.argv[4]) if len(sys.argv) > 4 else -2
+a, b = spans[which] if len(spans) > 1 else spans[-1]
 step = rows[a:b]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 agg = collections.OrderedDict()
