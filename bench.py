@@ -522,10 +522,10 @@ def main():
                        chunk_tokens=int(chunk_tokens), chunks_timed=len(steady),
                        roofline=dict(bound="mfma", achieved=round(chunk_flops / chunk_s / 1e12, 2), peak=MFMA_PEAK_TFLOPS,
                                      unit="TFLOP/s", frac=round(chunk_flops / chunk_s / 1e12 / MFMA_PEAK_TFLOPS, 4)),
-                       steps_in_flight=2 if (ahead and runner.step_overlap) else 1,
+                       steps_in_flight=runner.LANES if (ahead and runner.step_overlap) else 1,
                        note="one sequence per step, T=chunk_tokens new tokens, no cached prefix; eager launches, host included"
                             + (" (engine one step ahead: a chunk's time is the interval between consecutive completions"
-                               + ("; the chunk launched ahead runs on another stream, ordered against its predecessor per layer" if runner.step_overlap else "")
+                               + ("; chunks are launched up to steps_in_flight ahead, each on its own stream, ordered against its predecessor per layer" if runner.step_overlap else "")
                                + ")" if ahead else ""))
     else:
         prefill = dict(note="fewer than two chunks in the prefill of this batch: not timed")
