@@ -111,6 +111,30 @@ int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const void*
                                 const void* q_norm_weight, const void* k_norm_weight, float eps,
                                 const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
                                 void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, nvh_stream_t stream);
+/* RMSNorm as a row scale - no single counterpart in the reference: together these three replace, for prefill-sized steps,
+ * RMSNorm.add_rms_forward (layers/layernorm.py:31-46) followed by the projection that reads its output
+ * (QKVParallelLinear / MergedColumnParallelLinear, layers/linear.py).  The producer adds its product to the residual stream
+ * in place (the add of add_rms_forward, same rounding points) and leaves `parts` partial sums of squares per row; the
+ * consumers run over the un-normalised residual with the norm weight folded into `w_folded` (w[n][k] * norm[k], bf16)
+ * and multiply row m of the product by 1 / sqrt(sum_p row_sumsq[m][p] / K + norm_eps) before their usual epilogue.
+ * nvh_gemm_residual_rowsq_parts: partial sums per row the producer writes for this shape, 0 = shape not supported
+ * (supported: the shapes nvh_gemm_bf16_nt runs on its two-group 64 x 64 tiles, M % 64 == 0, N % 128 == 0).
+ * nvh_gemm_qkv_epilogue_in_gemm: 1 when nvh_gemm_qkv_rope_store runs its epilogue inside the GEMM for this shape (the
+ * row-scaled form exists only then; otherwise it returns NVH_ENOSYS). */
+int32_t nvh_gemm_residual_rowsq_parts(int64_t M, int64_t N, int64_t K);
+int32_t nvh_gemm_residual_rowsq_bf16_nt(const void* x, int64_t x_row_stride, const void* w, void* residual, float* row_sumsq,
+                                        int64_t M, int64_t N, int64_t K, nvh_stream_t stream);
+int32_t nvh_gemm_qkv_epilogue_in_gemm(int64_t M, int64_t N, int64_t K);
+int32_t nvh_gemm_qkv_rope_store_rowscaled(const void* x, int64_t x_row_stride, const void* w_folded, void* qkv, int64_t qkv_row_stride,
+                                          int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                          const void* q_norm_weight, const void* k_norm_weight, float eps,
+                                          const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
+                                          void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, const float* row_sumsq,
+                                          int32_t parts, float norm_eps, nvh_stream_t stream);
+int32_t nvh_gemm_swiglu_rowscaled_bf16_nt(const void* x, int64_t x_row_stride, const void* w_folded, void* y, int64_t y_row_stride,
+                                          int64_t M, int64_t N, int64_t K, const float* row_sumsq, int32_t parts, float norm_eps,
+                                          nvh_stream_t stream);
+
 
 /* ---- K7: SiLU(x[:, :I]) * x[:, I:].  layers/activation.py:36-58.  x [rows, 2I] -> y [rows, I]. */
 int32_t nvh_silu_mul(const void* x, void* y, int64_t rows, int64_t inter, nvh_stream_t stream);
@@ -379,6 +403,12 @@ typedef struct {
     void* const* k_cache;              /* [pages,256,Hkv,D] per layer, or NULL array entries before the pool exists */
     void* const* v_cache;
     nvh_comm* comm;                    /* NULL: single rank.  Else all sizes above are this rank's shard */
+    /* Optional (NULL: off): the QKV / gate-up weights with the RMSNorm weight of their input folded in
+     * (w[n][k] * norm[k] rounded to bf16; gate_up_scaled in nvh_interleave_gate_up order).  With both set, prefill-sized
+     * single-rank steps whose shapes allow it apply the two RMSNorms of a layer as a row scale inside the projection that
+     * consumes them (nvh_gemm_residual_rowsq_bf16_nt and the *_rowscaled entry points): two launches less per layer. */
+    const void* const* qkv_w_scaled;
+    const void* const* gate_up_scaled;
 } nvh_qwen3_model;
 
 #define NVH_MODE_PACKED 0   /* layers/attention.py: block_tables is None (K/V = new tokens) */

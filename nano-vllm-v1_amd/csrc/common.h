@@ -61,7 +61,7 @@ int32_t nvh_decode_arrivals(unsigned** out);
     X(KWAVES_NO_8) X(GEMM_S128) X(GEMM_S64) X(GEMM_NO_ROUND_CUT) X(GEMM_NO_16x64) X(GEMM_NO_KGROUPS)               \
     X(QKV_NO_8WAVE) X(SWIGLU_NO_192) X(SWIGLU_NO_96) X(NO_FUSED_QKV) X(NO_NORM_GEMM) X(NORM_GEMM_KB)               \
     X(NORM_GEMM_ROWS) X(DECODE_SLABS) X(NO_FUSED_EXCHANGE) X(NO_FUSED_DECODE)        \
-    X(LM_HEAD_NO_CUT) X(EXP_A) X(EXP_B)
+    X(LM_HEAD_NO_CUT) X(NO_ROWSCALE) X(EXP_A) X(EXP_B)
 enum NvhSwitch : int {
 #define NVH_SW_ENUM(n) SW_##n,
     NVH_SWITCHES(NVH_SW_ENUM)

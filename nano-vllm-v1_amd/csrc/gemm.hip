@@ -72,6 +72,17 @@ struct SampleEpilogue {
     int cand_base;            // this launch's first slot in a row's candidates
 };
 
+// RMSNorm as a row scale (QKV and SwiGLU epilogues of prefill-sized steps): the projection runs over the UN-normalised
+// rows with the norm weight folded into its weight matrix (W' = W * w along K), and every accumulator of row m is
+// multiplied by 1 / sqrt(sum(x_m^2) / K + eps) before the epilogue proper.  sum(x_m^2) arrives as `parts` partial sums per
+// row, left by the epilogue of the projection that produced x (nvh_gemm_residual_rowsq_bf16_nt); they are added in
+// index order.  sumsq == nullptr: no scaling.
+struct RowScale {
+    const float* sumsq;       // [M][parts]
+    int parts;                // multiple of 4
+    float inv_k, eps;
+};
+
 // Tile of this workgroup.  Workgroups go to the 8 XCDs round-robin by linear id.  With xcd_strip = 8 or 4 (host: gridDim.x a
 // multiple of it) XCD i takes the i-th eighth of the tiles in an order that walks strips of that many column tiles row
 // by row, so the workgroups resident on an XCD at one time share a few column tiles of W and a few row tiles of x in
@@ -95,7 +106,7 @@ template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool 
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split,
-    QkvEpilogue qe, bool wide_store, SampleEpilogue se, int xcd_strip) {
+    QkvEpilogue qe, bool wide_store, SampleEpilogue se, int xcd_strip, RowScale rs) {
     constexpr int NW = WAVES_N * WAVES_M;                 // waves per workgroup (4; 2 for the skinny decode tiles)
     static_assert(NW == 8 || NW == 4 || NW == 2, "2, 4 or 8 waves");
     constexpr int WN = BN / WAVES_N, WM = BM / WAVES_M;   // wave tile
@@ -183,6 +194,66 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+    // Row scales of this lane's TM rows (see RowScale).  Eight-wave tiles (the only ones the step executor sends here) request
+    // the partial sums ahead of the main loop with loads the compiler does not track and first look at them in the
+    // epilogue: up to 32 partial sums per row wait in registers, and their latency - the rows were written by the kernel
+    // before this one, on other XCDs - hides behind the loop instead of delaying its start by ~3 us.  Other tiles read
+    // them in the epilogue.
+    constexpr bool RS = QKV || SWIGLU;
+    constexpr bool RS_EARLY = RS && NW == 8 && TM == 2;
+    // (the four lanes fq = 0..3 that share a row split its partial sums: lane fq takes groups fq and fq + 4 of four)
+    f32x4 rsq[RS_EARLY ? TM * 2 : 1];
+    if constexpr (RS_EARLY) {
+        if (rs.sumsq != nullptr) {                           // block-uniform
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const float* ps = rs.sumsq + (int64_t)min(m0 + wm * WM + j * 16 + fr, M - 1) * rs.parts;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float* pa = ps + 4 * min(fq + 4 * u, (rs.parts >> 2) - 1);      // (groups past parts / 4 re-read the last one and are not added)
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rsq[j * 2 + u]) : "v"(pa) : "memory");
+                }
+            }
+        }
+    }
+    auto row_scales = [&](float (&rscale)[TM]) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) rscale[j] = 1.0f;
+        if constexpr (RS) {
+            if (rs.sumsq != nullptr) {
+                if constexpr (RS_EARLY) {
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsq[0]), "+v"(rsq[1]), "+v"(rsq[2]), "+v"(rsq[3])::"memory");
+                }
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    float ss = 0.f;
+                    if constexpr (RS_EARLY) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (fq + 4 * u < (rs.parts >> 2)) {
+                                const f32x4 v = rsq[j * 2 + u];
+                                ss += v[0];
+                                ss += v[1];
+                                ss += v[2];
+                                ss += v[3];
+                            }
+                        ss += __shfl_xor(ss, 16, 64);
+                        ss += __shfl_xor(ss, 32, 64);
+                    } else {
+                        const f32x4* ps = reinterpret_cast<const f32x4*>(rs.sumsq + (int64_t)min(m0 + wm * WM + j * 16 + fr, M - 1) * rs.parts);
+                        for (int q = 0; q < (rs.parts >> 2); ++q) {
+                            const f32x4 v = ps[q];
+                            ss += v[0];
+                            ss += v[1];
+                            ss += v[2];
+                            ss += v[3];
+                        }
+                    }
+                    rscale[j] = 1.0f / sqrtf(ss * rs.inv_k + rs.eps);
+                }
+            }
+        }
+    };
     if constexpr (NW == 8) {
         // Eight waves, two per SIMD.  Every wave runs the same four phases per k-tile, a barrier before each:
         //   READ k0 (12 fragment reads) | MFMA k0 (32) | READ k1 | MFMA k1
@@ -358,6 +429,8 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
                 cs[p][3] = *reinterpret_cast<const f32x4*>(cs_row + 68);
             }
         }
+        float rscale[TM];
+        row_scales(rscale);
         __syncthreads();                                         // every wave is done with the last stage
         bf16* tile = reinterpret_cast<bf16*>(smem);              // [BM][TS]
 #pragma unroll
@@ -367,7 +440,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
                 const int row = wm * WM + j * 16 + fr, col = wn * WN + i * 16 + fq * 4;
                 bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e]);
+                for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[i][j][e] * rscale[j]);
                 *reinterpret_cast<bf16x4*>(tile + row * TS + col) = o;
             }
         __syncthreads();
@@ -400,6 +473,8 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
         // gate and tile i+1 the matching up columns in the same lanes.  y[m][16b + ..] = silu(gate) * up with the
         // rounding points of the separate kernels: GEMM output -> bf16, silu -> bf16, product -> bf16.
         // pairs of 16-row tiles: configurations with an odd TN are never launched with SWIGLU (dispatch_gemm)
+        float rscale[TM];
+        row_scales(rscale);
 #pragma unroll
         for (int i = 0; i + 1 < TN; i += 2) {
             const int n = n0 + wn * WN + i * 16;                 // first interleaved row of the gate block
@@ -412,8 +487,8 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float gv = bf2f(f2bf(acc[i][j][e]));
-                    const float uv = bf2f(f2bf(acc[i + 1][j][e]));
+                    const float gv = bf2f(f2bf(acc[i][j][e] * rscale[j]));
+                    const float uv = bf2f(f2bf(acc[i + 1][j][e] * rscale[j]));
                     const float sl = gv / (1.0f + expf(-gv));
                     o[e] = f2bf(bf2f(f2bf(sl)) * uv);
                 }
@@ -497,7 +572,7 @@ template <int STAGES>
 __global__ __launch_bounds__(512) void gemm_kgroups_bf16_nt_kernel(const bf16* __restrict__ x, int64_t x_stride,
                                                                    const bf16* __restrict__ w, const bf16* __restrict__ bias,
                                                                    bf16* __restrict__ y, int64_t y_stride, int M, int N, int K,
-                                                                   int xcd_strip) {
+                                                                   int xcd_strip, bf16* __restrict__ residual, float* __restrict__ row_sumsq) {
     constexpr int BM = 64, BN = 64, NW = 8, TN = 2, TM = 2;
     constexpr int A_BYTES = BN * 128, B_BYTES = BM * 128, TILE_BYTES = A_BYTES + B_BYTES, STAGE_BYTES = 2 * TILE_BYTES;
     constexpr int GROUPS8 = BN / 8 + BM / 8;
@@ -539,6 +614,18 @@ __global__ __launch_bounds__(512) void gemm_kgroups_bf16_nt_kernel(const bf16* _
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fq = lane >> 4;
+    // residual mode: this lane's 16 residual elements, requested ahead of the main loop by loads the compiler does not track
+    // (first looked at in the epilogue, behind a wait of their own)
+    bf16x4 res_pre[TN][TM];
+    if (residual != nullptr && grp == 0) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const bf16* rp = residual + (int64_t)(m0 + wm * 32 + j * 16 + fr) * N + n0 + wn * 32 + i * 16 + fq * 4;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(res_pre[i][j]) : "v"(rp) : "memory");
+            }
+    }
     for (int t = 0; t < AHEAD && t < nstages; ++t) stage(t);
     for (int t = 0; t < nstages; ++t) {
         wait_tiles_in_flight<PW, (AHEAD > 0 ? AHEAD - 1 : 0)>(min(AHEAD - 1, nstages - 1 - t));
@@ -579,6 +666,44 @@ __global__ __launch_bounds__(512) void gemm_kgroups_bf16_nt_kernel(const bf16* _
     }
     __syncthreads();
     if (grp == 1) return;
+    if (residual != nullptr) {
+        // The product is added to the residual stream in place (y is not written) with the arithmetic of the add + RMSNorm
+        // launch that would follow: product rounded to bf16, sum in fp32, new residual = that sum rounded to bf16; and the
+        // fp32 sums' squares are added up per row over this wave's 32 columns: row_sumsq[m][2 * column tile + wn], for the
+        // consumer that applies the norm as a row scale (RowScale).  Whole tiles only (host-checked).
+        float sq[TM];
+#pragma unroll
+        for (int j = 0; j < TM; ++j) sq[j] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(res_pre[0][0]), "+v"(res_pre[0][1]), "+v"(res_pre[1][0]), "+v"(res_pre[1][1])::"memory");
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + wn * 32 + i * 16 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = m0 + wm * 32 + j * 16 + fr;
+                const f32x4 other = red[(w4 * TN * TM + i * TM + j) * 64 + lane];
+                bf16* rp = residual + (int64_t)m * N + n;
+                const bf16x4 r4 = res_pre[i][j];
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xs = bf2f(f2bf(acc[i][j][e] + other[e])) + bf2f(r4[e]);
+                    sq[j] += xs * xs;
+                    o[e] = f2bf(xs);
+                }
+                *reinterpret_cast<bf16x4*>(rp) = o;
+            }
+        }
+        const int parts = 2 * (int)gridDim.x;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            float t = sq[j];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (fq == 0) row_sumsq[(int64_t)(m0 + wm * 32 + j * 16 + fr) * parts + 2 * bx + wn] = t;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
         const int n = n0 + wn * 32 + i * 16 + fq * 4;
@@ -1013,6 +1138,9 @@ struct GemmArgs {
     const SampleEpilogue* sample = nullptr;   // set: the sampling epilogue (256x256 tiles only)
     char* plan = nullptr;               // set: launch nothing, append the name of every launch that would be made (nvh_gemm_plan)
     size_t plan_bytes = 0;
+    RowScale rowscale = RowScale{nullptr, 0, 0.f, 0.f};   // QKV / SwiGLU epilogues: RMSNorm as a row scale
+    bf16* residual = nullptr;           // set (with row_sumsq): add the product to this [M, N] residual in place (two-group 64 x 64 tiles only)
+    float* row_sumsq = nullptr;
 };
 
 // nvh_gemm_plan: one entry per launch, "; " between them
@@ -1053,7 +1181,7 @@ void launch_gemm_nt(const GemmArgs& a) {
     // prefill-sized products only: at 256 rows (a decode batch, 64-row tiles) the same order made a step 0.7 % slower
     const int xcd_strip = (no_xcd || grid.y * grid.z == 1 || a.M < 512) ? 0 : grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 0;
     kern<<<grid, 64 * WAVES_N * WAVES_M, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.partials, a.M, a.N, a.K, k_per_split,
-                                                       a.qkv ? *a.qkv : QkvEpilogue{}, wide, a.sample ? *a.sample : SampleEpilogue{}, xcd_strip);
+                                                       a.qkv ? *a.qkv : QkvEpilogue{}, wide, a.sample ? *a.sample : SampleEpilogue{}, xcd_strip, a.rowscale);
 }
 
 void launch_gemm_kgroups(const GemmArgs& a) {
@@ -1065,13 +1193,13 @@ void launch_gemm_kgroups(const GemmArgs& a) {
         configured = true;
     }
     if (a.plan) {
-        plan_note(a, "kgroups 64x64 stages %d grid %ldx%ld", STAGES, (long)nvh_cdiv(a.N, 64), (long)nvh_cdiv(a.M, 64));
+        plan_note(a, "kgroups 64x64 stages %d%s grid %ldx%ld", STAGES, a.residual ? " residual" : "", (long)nvh_cdiv(a.N, 64), (long)nvh_cdiv(a.M, 64));
         return;
     }
     dim3 grid((unsigned)nvh_cdiv(a.N, 64), (unsigned)nvh_cdiv(a.M, 64), 1);
     const bool no_xcd = nvh_switch_on(SW_GEMM_NO_XCD);
     const int xcd_strip = (no_xcd || grid.y == 1 || a.M < 512) ? 0 : grid.x % 8 == 0 ? 8 : grid.x % 4 == 0 ? 4 : 0;   // as launch_gemm_nt
-    kern<<<grid, 512, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M, a.N, a.K, xcd_strip);
+    kern<<<grid, 512, smem, a.st>>>(a.x, a.xs, a.w, a.bias, a.y, a.ys, a.M, a.N, a.K, xcd_strip, a.residual, a.row_sumsq);
 }
 
 template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES>
@@ -1226,6 +1354,13 @@ extern "C" int32_t nvh_gemm_bf16_nt(const void* x, int64_t x_row_stride, const v
 // 5120 at 1..32 rows: 2.2-8.7 us against 2.8-19 us for K = 256..4096; N = 5120 at 32 rows, 640 workgroups: slower).
 // Only from K = 1536: below that a gate/up projection could take it, and its sum over K would no longer be the one of the
 // SwiGLU kernel (nvh_gemm_swiglu_bf16_nt promises the bits of nvh_gemm_bf16_nt + nvh_silu_mul).
+// Shapes that take the two-group 64 x 64 tiles (see gemm_kgroups_bf16_nt_kernel): a plain product whose 64 x 64 grid is
+// one nearly full round.
+static bool takes_kgroups(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles64 = nvh_cdiv(M, 64) * nvh_cdiv(N, 64);
+    return !nvh_switch_on(SW_GEMM_NO_KGROUPS) && M > 64 && K % 128 == 0 && K >= 1024 && tiles64 >= 200 && tiles64 <= 256;
+}
+
 static bool takes_kwaves(const GemmArgs& a) {
     const bool off = nvh_switch_on(SW_NO_KWAVES);                   // A/B switch for measurements
     const int kmin = (int)nvh_switch_or(SW_KWAVES_KMIN, 1536);   // tuning switch
@@ -1330,9 +1465,8 @@ static int32_t dispatch_gemm(const GemmArgs& a) {
         case T32x128: launch_gemm<32, 128, 4, 1, 4>(a); break;
         case T64x128: launch_gemm<64, 128, 2, 2, 4>(a); break;
         case T64x64: {
-            const int64_t tiles64 = nvh_cdiv(a.M, 64) * nvh_cdiv(a.N, 64);
-            if (!nvh_switch_on(SW_GEMM_NO_KGROUPS) && !a.swiglu && a.qkv == nullptr && a.sample == nullptr && a.split_k == 1 && a.partials == nullptr &&
-                a.y != nullptr && a.M > 64 && a.K % 128 == 0 && a.K >= 1024 && tiles64 >= 200 && tiles64 <= 256)
+            if (!a.swiglu && a.qkv == nullptr && a.sample == nullptr && a.split_k == 1 && a.partials == nullptr &&
+                (a.y != nullptr || a.residual != nullptr) && takes_kgroups(a.M, a.N, a.K))
                 launch_gemm_kgroups(a);
             else launch_gemm<64, 64, 2, 2, 4>(a);
             break;
@@ -1446,11 +1580,16 @@ extern "C" int32_t nvh_gemm_swiglu_bf16_nt(const void* x, int64_t x_row_stride, 
 // qkv[M, (Hq + 2 Hkv) * 128] = x W^T followed by the q/k epilogue (per-head RMSNorm, RoPE) and the KV-cache store of
 // rows raw_rows.. - in the GEMM's own epilogue when the shape takes 128 x 128 tiles (one head per tile), otherwise
 // as nvh_gemm_bf16_nt + nvh_qknorm_rope_store.  Both routes give the same bits.
-extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const void* w, void* qkv, int64_t qkv_row_stride,
-                                           int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
-                                           const void* q_norm_weight, const void* k_norm_weight, float eps,
-                                           const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
-                                           void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, nvh_stream_t stream) {
+static bool qkv_epilogue_in_gemm(int64_t M, int64_t N, int64_t K) {
+    return M > 0 && !nvh_switch_on(SW_NO_FUSED_QKV) && K > 0 && K % BK == 0 && M < (1 << 30) && pick_tile(M, N, 1) == T128x128 &&
+           nvh_cdiv(M, 128) * nvh_cdiv(N, 128) <= 256;   // one workgroup per CU: the epilogue's registers cost no occupancy (two per CU, the Qwen3-14B shape's 448 tiles: a chunk 27.1 -> 28.9 ms)
+}
+
+static int32_t gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const void* w, void* qkv, int64_t qkv_row_stride,
+                                   int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                   const void* q_norm_weight, const void* k_norm_weight, float eps,
+                                   const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
+                                   void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, const RowScale& rs, nvh_stream_t stream) {
     NVH_REQUIRE(x && w && qkv && q_norm_weight && k_norm_weight && positions && cos_sin, NVH_EINVAL, "nvh_gemm_qkv_rope_store: null pointer");
     NVH_REQUIRE(head_dim == 128, NVH_ENOSYS, "nvh_gemm_qkv_rope_store: head_dim %ld unsupported (128 only)", (long)head_dim);
     NVH_REQUIRE(num_q_heads > 0 && num_kv_heads > 0 && raw_rows >= 0 && raw_rows <= M, NVH_EINVAL, "nvh_gemm_qkv_rope_store: heads / raw_rows out of range");
@@ -1459,21 +1598,88 @@ extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, 
     NVH_REQUIRE(qkv_row_stride % 8 == 0 && nvh_aligned16(qkv) && nvh_aligned16(cos_sin) && nvh_aligned16(q_norm_weight) && nvh_aligned16(k_norm_weight) &&
                     (!k_cache || (nvh_aligned16(k_cache) && nvh_aligned16(v_cache))),
                 NVH_EINVAL, "nvh_gemm_qkv_rope_store: 16-byte alignment required");
-    const bool no_fuse = nvh_switch_on(SW_NO_FUSED_QKV);            // A/B switch for measurements
-    if (M > 0 && !no_fuse && K > 0 && K % BK == 0 && M < (1 << 30) && x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w) &&
-        pick_tile(M, N, 1) == T128x128 && nvh_cdiv(M, 128) * nvh_cdiv(N, 128) <= 256) {   // one workgroup per CU: the epilogue's registers cost no occupancy (two per CU, the Qwen3-14B shape's 448 tiles: a chunk 27.1 -> 28.9 ms)
+    if (qkv_epilogue_in_gemm(M, N, K) && x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w)) {
         const bool store = k_cache && slot_mapping;
         QkvEpilogue qe{(const bf16*)q_norm_weight, (const bf16*)k_norm_weight, positions, cos_sin, store ? (bf16*)k_cache : nullptr,
                        store ? (bf16*)v_cache : nullptr, store ? slot_mapping : nullptr, eps, (int)num_q_heads, (int)num_kv_heads, (int)raw_rows};
         GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, (bf16*)qkv, nullptr, x_row_stride, qkv_row_stride, (int)M, (int)N, (int)K, 1,
                    (hipStream_t)stream, false, &qe};
+        a.rowscale = rs;
         return dispatch_gemm(a);
     }
+    NVH_REQUIRE(rs.sumsq == nullptr, NVH_ENOSYS, "nvh_gemm_qkv_rope_store_rowscaled: this shape does not take the epilogue inside the GEMM (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
     const int32_t rc = nvh_gemm_bf16_nt(x, x_row_stride, w, nullptr, qkv, qkv_row_stride, M, N, K, 1, nullptr, stream);
     if (rc != NVH_OK || M == raw_rows) return rc;
     return nvh_qknorm_rope_store((bf16*)qkv + raw_rows * qkv_row_stride, qkv_row_stride, num_q_heads, num_kv_heads, q_norm_weight, k_norm_weight,
                                  eps, positions + raw_rows, cos_sin, max_position, k_cache, v_cache, slot_mapping ? slot_mapping + raw_rows : nullptr,
                                  M - raw_rows, stream);
+}
+
+extern "C" int32_t nvh_gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const void* w, void* qkv, int64_t qkv_row_stride,
+                                           int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                           const void* q_norm_weight, const void* k_norm_weight, float eps,
+                                           const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
+                                           void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, nvh_stream_t stream) {
+    return gemm_qkv_rope_store(x, x_row_stride, w, qkv, qkv_row_stride, M, K, num_q_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, eps,
+                               positions, cos_sin, max_position, k_cache, v_cache, slot_mapping, raw_rows, RowScale{nullptr, 0, 0.f, 0.f}, stream);
+}
+
+// ---- RMSNorm as a row scale (prefill-sized steps): three entry points that together replace
+//   add + RMSNorm launch -> projection        by        projection over the un-normalised residual, scaled per row.
+// nvh_gemm_residual_rowsq_bf16_nt is the producer: residual += x W^T in place (product rounded to bf16 first, sum in fp32,
+// rounded to bf16: the arithmetic of nvh_add_rmsnorm's add) and row_sumsq[m][p], p < parts, = partial sums of the squares of
+// the fp32 sums of row m.  The two consumers take `w` with the norm weight folded in (w[n][k] * norm_weight[k], rounded
+// to bf16) and multiply row m of the product by 1 / sqrt(sum_p row_sumsq[m][p] / K + norm_eps) before their epilogue.
+// Against the separate launches the rounding points move (the normalised row is never rounded to bf16; the folded
+// weight is): same tolerance against an fp32 reference, not the same bits.
+extern "C" int32_t nvh_gemm_residual_rowsq_parts(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K <= 0 || M % 64 || N % 128 || K % BK || M >= (1 << 30) || N >= (1 << 30)) return 0;
+    return pick_tile(M, N, 1) == T64x64 && takes_kgroups(M, N, K) ? (int32_t)(N / 32) : 0;
+}
+
+extern "C" int32_t nvh_gemm_residual_rowsq_bf16_nt(const void* x, int64_t x_row_stride, const void* w, void* residual, float* row_sumsq,
+                                                   int64_t M, int64_t N, int64_t K, nvh_stream_t stream) {
+    NVH_REQUIRE(x && w && residual && row_sumsq, NVH_EINVAL, "nvh_gemm_residual_rowsq_bf16_nt: null pointer");
+    NVH_REQUIRE(nvh_gemm_residual_rowsq_parts(M, N, K) > 0, NVH_ENOSYS,
+                "nvh_gemm_residual_rowsq_bf16_nt: M=%ld N=%ld K=%ld does not take the two-group 64 x 64 tiles (nvh_gemm_residual_rowsq_parts)", (long)M, (long)N, (long)K);
+    NVH_REQUIRE(x_row_stride % 8 == 0 && nvh_aligned16(x) && nvh_aligned16(w) && nvh_aligned16(residual) && nvh_aligned16(row_sumsq), NVH_EINVAL,
+                "nvh_gemm_residual_rowsq_bf16_nt: alignment");
+    GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, nullptr, nullptr, x_row_stride, N, (int)M, (int)N, (int)K, 1, (hipStream_t)stream, false};
+    a.residual = (bf16*)residual;
+    a.row_sumsq = row_sumsq;
+    return dispatch_gemm(a);
+}
+
+extern "C" int32_t nvh_gemm_qkv_epilogue_in_gemm(int64_t M, int64_t N, int64_t K) { return qkv_epilogue_in_gemm(M, N, K) ? 1 : 0; }
+
+extern "C" int32_t nvh_gemm_qkv_rope_store_rowscaled(const void* x, int64_t x_row_stride, const void* w_folded, void* qkv, int64_t qkv_row_stride,
+                                                     int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
+                                                     const void* q_norm_weight, const void* k_norm_weight, float eps,
+                                                     const int64_t* positions, const float* cos_sin, int64_t max_position, void* k_cache,
+                                                     void* v_cache, const int32_t* slot_mapping, int64_t raw_rows, const float* row_sumsq,
+                                                     int32_t parts, float norm_eps, nvh_stream_t stream) {
+    NVH_REQUIRE(row_sumsq && parts > 0 && parts % 4 == 0 && nvh_aligned16(row_sumsq), NVH_EINVAL, "nvh_gemm_qkv_rope_store_rowscaled: row sums missing or parts %% 4 != 0");
+    NVH_REQUIRE(parts <= 32, NVH_ENOSYS, "nvh_gemm_qkv_rope_store_rowscaled: at most 32 partial sums per row (%d)", parts);
+    return gemm_qkv_rope_store(x, x_row_stride, w_folded, qkv, qkv_row_stride, M, K, num_q_heads, num_kv_heads, head_dim, q_norm_weight, k_norm_weight, eps,
+                               positions, cos_sin, max_position, k_cache, v_cache, slot_mapping, raw_rows,
+                               RowScale{row_sumsq, parts, 1.0f / (float)K, norm_eps}, stream);
+}
+
+extern "C" int32_t nvh_gemm_swiglu_rowscaled_bf16_nt(const void* x, int64_t x_row_stride, const void* w_folded, void* y, int64_t y_row_stride,
+                                                     int64_t M, int64_t N, int64_t K, const float* row_sumsq, int32_t parts, float norm_eps,
+                                                     nvh_stream_t stream) {
+    NVH_REQUIRE(x && w_folded && y, NVH_EINVAL, "nvh_gemm_swiglu_rowscaled_bf16_nt: null pointer");
+    NVH_REQUIRE(row_sumsq && parts > 0 && parts % 4 == 0 && nvh_aligned16(row_sumsq), NVH_EINVAL, "nvh_gemm_swiglu_rowscaled_bf16_nt: row sums missing or parts %% 4 != 0");
+    NVH_REQUIRE(parts <= 32, NVH_ENOSYS, "nvh_gemm_swiglu_rowscaled_bf16_nt: at most 32 partial sums per row (%d)", parts);
+    NVH_REQUIRE(K > 0 && K % BK == 0 && N > 0 && N % 32 == 0, NVH_EINVAL, "nvh_gemm_swiglu_rowscaled_bf16_nt: K %% 64 and N %% 32 required (K=%ld N=%ld)", (long)K, (long)N);
+    NVH_REQUIRE(M >= 0 && M < (1 << 30) && N < (1 << 30), NVH_EINVAL, "nvh_gemm_swiglu_rowscaled_bf16_nt: M/N out of range");
+    NVH_REQUIRE(x_row_stride % 8 == 0 && y_row_stride % 4 == 0 && nvh_aligned16(x) && nvh_aligned16(w_folded) && ((uintptr_t)y & 7) == 0,
+                NVH_EINVAL, "nvh_gemm_swiglu_rowscaled_bf16_nt: alignment");
+    if (M == 0) return NVH_OK;
+    GemmArgs a{(const bf16*)x, (const bf16*)w_folded, nullptr, (bf16*)y, nullptr, x_row_stride, y_row_stride, (int)M, (int)N, (int)K, 1,
+               (hipStream_t)stream, true};
+    a.rowscale = RowScale{row_sumsq, parts, 1.0f / (float)K, norm_eps};
+    return dispatch_gemm(a);
 }
 
 // ---- residual add + RMSNorm + projection in one launch (decode batches)

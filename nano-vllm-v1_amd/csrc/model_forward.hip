@@ -205,6 +205,16 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
         const int swaps = (fuse_in ? in_sites : 0) + (fuse_post ? post_sites : 0);
         return (swaps & 1) ? w.residual2 : w.residual;
     };
+    // Prefill-sized single-rank steps: the two RMSNorms of a layer as a row scale inside the projections that consume them
+    // (see nvh_gemm_residual_rowsq_bf16_nt).  The O and down projections add their product to the residual stream in place and
+    // leave per-row sums of squares (in w.y: those projections write no bf16 result on this route), the QKV and gate/up
+    // projections read the residual itself with the folded weights.  Layer 0's input norm stays a launch (the embedding
+    // leaves no sums), the final norm becomes a plain RMSNorm of the residual.
+    const int32_t parts_o = nvh_gemm_residual_rowsq_parts(t, h, qsz), parts_d = nvh_gemm_residual_rowsq_parts(t, h, md->inter);
+    const bool rowscale = !nvh_switch_on(SW_NO_ROWSCALE) && md->qkv_w_scaled && md->gate_up_scaled && md->gate_up_inter && !sharded && t > 64 &&
+                          so == 1 && sd == 1 && sq == 1 && d == 128 && st->mode != NVH_MODE_DECODE && t > prefix && parts_o > 0 && parts_d > 0 && parts_o <= 32 && parts_d <= 32 &&
+                          nvh_gemm_qkv_epilogue_in_gemm(t, qkv_n, h) && (int64_t)(parts_o > parts_d ? parts_o : parts_d) * 4 <= h * 2;
+    float* const rowsq = reinterpret_cast<float*>(w.y);
     for (int l = 0; l < md->layers; ++l) {
       if (runs(2 * l + 1)) {
         // the step before this one (on another stream) is done with the attention of this layer: its keys are in the
@@ -213,7 +223,9 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
         // ---- input norm: layer 0 normalises the embedding; later layers add the MLP output first
         bf16* const res = residual_after(l, l);                     // input sites of layers 0..l-1, post sites of layers 0..l-1
         bool qkv_done = false;
-        if (fuse_in) {
+        if (rowscale && l > 0) {
+            // (the down projection of layer l - 1 has added its product to `res` and left the row sums)
+        } else if (fuse_in) {
             // (layer 0: nothing to add - the embedding rows are the residual stream)
             FWD(nvh_add_rmsnorm_gemm_bf16_nt(l == 0 ? nullptr : pending_y, l > 0 && pending_slabs ? w.slabs : nullptr, l == 0 ? 0 : pending_count, res,
                                              residual_after(l + 1, l), md->input_norm[l], md->eps, md->qkv_w[l], w.qkv, qkv_n, t, qkv_n, h, 0, stream));
@@ -238,6 +250,11 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
         } else if (sq > 1) {
             FWD(nvh_gemm_bf16_nt(w.x, h, md->qkv_w[l], nullptr, nullptr, qkv_n, t, qkv_n, h, sq, w.slabs, stream));
             FWD(nvh_splitk_reduce(w.slabs, sq, nullptr, w.qkv, qkv_n, t, qkv_n, stream));
+        } else if (rowscale && l > 0) {
+            FWD(nvh_gemm_qkv_rope_store_rowscaled(res, h, md->qkv_w_scaled[l], w.qkv, qkv_n, t, h, hq, hkv, d, md->q_norm[l], md->k_norm[l], md->eps,
+                                                  st->positions, md->cos_sin, md->max_position, store ? kc : nullptr, store ? vc : nullptr,
+                                                  store ? st->slot_mapping : nullptr, prefix, rowsq, parts_d, md->eps, stream));
+            qk_done = true;
         } else if (!decode_fused && t > prefix && d == 128) {
             // projection + q/k norm + RoPE + KV store in one call (one launch when the shape takes 128x128 tiles)
             FWD(nvh_gemm_qkv_rope_store(w.x, h, md->qkv_w[l], w.qkv, qkv_n, t, h, hq, hkv, d, md->q_norm[l], md->k_norm[l], md->eps,
@@ -275,13 +292,18 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
         }
         if (ev_record) HIPCHK(hipEventRecord(ev_record[l], (hipStream_t)stream), "nvh_qwen3_forward: layer event record");
         // ---- O projection
-        if (so > 1) FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, nullptr, h, t, h, qsz, so, w.slabs, stream));
+        if (rowscale) FWD(nvh_gemm_residual_rowsq_bf16_nt(w.attn, qsz, md->o_w[l], residual_after(l + 1, l), rowsq, t, h, qsz, stream));
+        else if (so > 1) FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, nullptr, h, t, h, qsz, so, w.slabs, stream));
         else FWD(nvh_gemm_bf16_nt(w.attn, qsz, md->o_w[l], nullptr, proj_out, h, t, h, qsz, 1, nullptr, stream));
       }
       if (runs(2 * l + 2)) {
         // ---- add + norm
         bf16* const res = residual_after(l + 1, l);                 // input sites of layers 0..l, post sites of layers 0..l-1
         const bool interleaved = md->gate_up_inter && md->gate_up_inter[l];
+        if (rowscale) {
+            FWD(nvh_gemm_swiglu_rowscaled_bf16_nt(res, h, md->gate_up_scaled[l], w.act, md->inter, t, 2 * md->inter, h, rowsq, parts_o, md->eps, stream));
+            FWD(nvh_gemm_residual_rowsq_bf16_nt(w.act, md->inter, md->down_w[l], res, rowsq, t, h, md->inter, stream));
+        } else {
         if (fuse_post) {
             FWD(nvh_add_rmsnorm_gemm_bf16_nt(so > 1 ? nullptr : w.y, so > 1 ? w.slabs : nullptr, so > 1 ? so : 0, res, residual_after(l + 1, l + 1),
                                              md->post_norm[l], md->eps, interleaved ? md->gate_up_inter[l] : md->gate_up_w[l],
@@ -313,11 +335,14 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
             FWD(nvh_gemm_bf16_nt(w.act, md->inter, md->down_w[l], nullptr, proj_out, h, t, h, md->inter, 1, nullptr, stream));
             if (comm && !fused_exchange) FWD(nvh_allreduce_bf16(comm, proj_out, w.y, t * h, stream));
         }
+        }
       }
     }
     if (runs(2 * md->layers + 1)) {
         bf16* const res = residual_after(md->layers, md->layers);
-        if (comm && fused_exchange) {
+        if (rowscale) {
+            FWD(nvh_rmsnorm(res, h, md->final_norm, hidden_out, h, t, h, md->eps, stream));
+        } else if (comm && fused_exchange) {
             FWD(nvh_allreduce_add_rmsnorm_bf16(comm, proj_out, res, md->final_norm, hidden_out, t, h, md->eps, stream));
         } else {
             FWD(nvh_add_rmsnorm(pending_y, res, md->final_norm, hidden_out, t, h, md->eps,

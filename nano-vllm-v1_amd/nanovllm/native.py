@@ -7,6 +7,7 @@ descriptor then holds the rank's shard sizes and the exchange handle."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -23,7 +24,8 @@ class ModelDesc(C.Structure):
                 ("inter", i32), ("vocab_rows", i32), ("vocab_start", i32), ("eps", f32), ("reserved2", i32),
                 ("max_position", i64), ("embed", vp), ("final_norm", vp), ("lm_head", vp), ("cos_sin", vp),
                 ("qkv_w", PP), ("o_w", PP), ("q_norm", PP), ("k_norm", PP), ("gate_up_w", PP), ("gate_up_inter", PP), ("down_w", PP),
-                ("input_norm", PP), ("post_norm", PP), ("k_cache", PP), ("v_cache", PP), ("comm", vp)]
+                ("input_norm", PP), ("post_norm", PP), ("k_cache", PP), ("v_cache", PP), ("comm", vp),
+                ("qkv_w_scaled", PP), ("gate_up_scaled", PP)]
 
 
 class StepDesc(C.Structure):
@@ -99,6 +101,30 @@ class NativeQwen3:
         else:
             self._inter = None
             d.gate_up_inter = None
+        # RMSNorm as a row scale (prefill-sized steps on one rank, hidden sizes whose O / down projections take the kernel that
+        # leaves the row sums): copies of the QKV and gate/up weights with the norm weight of their input folded in
+        self.rowscale = (self.comm is None and self.reduce_fn is None and self._inter is not None and d.hidden <= 2048
+                         and os.environ.get("NANOVLLM_ROWSCALE", "1") != "0"
+                         and any(self.lib.nvh_gemm_residual_rowsq_parts(mm, d.hidden, d.num_q_heads * d.head_dim) > 0 for mm in range(64, 4097, 64)))
+        if self.rowscale:
+            prev_q = getattr(self, "_qkv_scaled", None) or [None] * len(layers)
+            prev_g = getattr(self, "_gu_scaled", None) or [None] * len(layers)
+
+            def folded(weight, norm, out):
+                f = (weight.float() * norm.float()[None, :]).to(weight.dtype)
+                if out is None:
+                    return f
+                out.copy_(f)              # refreshed IN PLACE on later rebuilds, like the interleaved copies
+                return out
+
+            self._qkv_scaled = [folded(l.self_attn.qkv_proj.weight.data, l.input_layernorm.weight.data, p) for l, p in zip(layers, prev_q)]
+            self._gu_scaled = [folded(w, l.post_attention_layernorm.weight.data, p) for w, l, p in zip(self._inter, layers, prev_g)]
+            d.qkv_w_scaled = arr("qkvs", self._qkv_scaled)
+            d.gate_up_scaled = arr("gus", self._gu_scaled)
+        else:
+            self._qkv_scaled = self._gu_scaled = None
+            d.qkv_w_scaled = None
+            d.gate_up_scaled = None
         d.down_w = arr("dn", [l.mlp.down_proj.weight for l in layers])
         d.input_norm = arr("in", [l.input_layernorm.weight for l in layers])
         d.post_norm = arr("pn", [l.post_attention_layernorm.weight for l in layers])

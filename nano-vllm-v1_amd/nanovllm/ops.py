@@ -108,6 +108,63 @@ def linear_qkv_rope_store(x, w, num_q_heads: int, num_kv_heads: int, q_weight, k
     return qkv
 
 
+# ---------------------------------------------------------------- RMSNorm as a row scale (prefill-sized steps)
+def residual_rowsq_parts(m: int, n: int, k: int) -> int:
+    """Partial sums of squares per row that `linear_add_residual_` leaves for this shape; 0: shape not supported."""
+    return int(_hip.lib().nvh_gemm_residual_rowsq_parts(m, n, k))
+
+
+def fold_norm_weight(weight: torch.Tensor, norm_weight: torch.Tensor) -> torch.Tensor:
+    """w[n][k] * norm[k] rounded to bf16: the projection weight the row-scaled entry points take."""
+    return (weight.float() * norm_weight.float()[None, :]).to(weight.dtype)
+
+
+def linear_add_residual_(x: torch.Tensor, weight: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+    """residual += x weight^T in place (product rounded to bf16, sum in fp32, rounded to bf16); returns the fp32 partial
+    sums of squares of the un-rounded sums, [M, parts]."""
+    _gpu_bf16(x, weight, residual)
+    m, k = x.shape
+    n = weight.shape[0]
+    parts = residual_rowsq_parts(m, n, k)
+    assert parts > 0 and residual.shape == (m, n) and residual.is_contiguous() and weight.is_contiguous() and x.stride(1) == 1
+    rowsq = torch.empty(m, parts, dtype=torch.float32, device=x.device)
+    _hip.call("nvh_gemm_residual_rowsq_bf16_nt", x.data_ptr(), x.stride(0), weight.data_ptr(), residual.data_ptr(), rowsq.data_ptr(),
+              m, n, k, _stream())
+    return rowsq
+
+
+def linear_swiglu_rowscaled(x: torch.Tensor, weight_folded_interleaved: torch.Tensor, rowsq: torch.Tensor, eps: float) -> torch.Tensor:
+    """silu(g) * u of (x w^T) * 1/sqrt(sum(rowsq[m]) / K + eps): RMSNorm + gate/up projection + SwiGLU over the
+    un-normalised rows, the norm weight folded into `weight_folded_interleaved`."""
+    _gpu_bf16(x, weight_folded_interleaved)
+    m, k = x.shape
+    n = weight_folded_interleaved.shape[0]
+    assert rowsq.dtype == torch.float32 and rowsq.shape[0] == m and rowsq.is_contiguous() and x.stride(1) == 1
+    y = torch.empty(m, n // 2, dtype=BF16, device=x.device)
+    _hip.call("nvh_gemm_swiglu_rowscaled_bf16_nt", x.data_ptr(), x.stride(0), weight_folded_interleaved.data_ptr(), y.data_ptr(), n // 2,
+              m, n, k, rowsq.data_ptr(), rowsq.shape[1], float(eps), _stream())
+    return y
+
+
+def linear_qkv_rope_store_rowscaled(x, w_folded, num_q_heads: int, num_kv_heads: int, q_weight, k_weight, eps: float, positions, cos_sin,
+                                    rowsq: torch.Tensor, norm_eps: float, k_cache=None, v_cache=None, slot_mapping=None,
+                                    raw_rows: int = 0) -> torch.Tensor:
+    """`linear_qkv_rope_store` over un-normalised rows (see linear_swiglu_rowscaled); only for shapes whose epilogue runs
+    inside the GEMM (HipError otherwise)."""
+    _gpu_bf16(x, w_folded, q_weight, k_weight)
+    t, k = x.shape
+    n = (num_q_heads + 2 * num_kv_heads) * 128
+    assert w_folded.shape == (n, k) and w_folded.is_contiguous() and x.stride(1) == 1 and positions.dtype == torch.int64
+    assert rowsq.dtype == torch.float32 and rowsq.shape[0] == t and rowsq.is_contiguous()
+    store = k_cache is not None and k_cache.numel() > 0 and slot_mapping is not None and slot_mapping.numel() > 0
+    qkv = torch.empty(t, n, dtype=BF16, device=x.device)
+    _hip.call("nvh_gemm_qkv_rope_store_rowscaled", x.data_ptr(), x.stride(0), w_folded.data_ptr(), qkv.data_ptr(), n, t, k, num_q_heads,
+              num_kv_heads, 128, q_weight.data_ptr(), k_weight.data_ptr(), float(eps), positions.data_ptr(), cos_sin.data_ptr(),
+              cos_sin.shape[0], k_cache.data_ptr() if store else 0, v_cache.data_ptr() if store else 0,
+              slot_mapping.data_ptr() if store else 0, raw_rows, rowsq.data_ptr(), rowsq.shape[1], float(norm_eps), _stream())
+    return qkv
+
+
 def store_kvcache(key, value, k_cache, v_cache, slot_mapping) -> None:
     _gpu_bf16(key, value, k_cache, v_cache)
     n, h, d = key.shape

@@ -201,6 +201,41 @@ def test_fused_qkv_epilogue_route_equals_two_launch_route(eager, tokens):
     greedy_agrees(b, a)
 
 
+@pytest.mark.parametrize("tokens,running", [(1024, 0), (896, 0), (1024, 9)])
+def test_rmsnorm_as_a_row_scale_route_agrees_with_the_norm_launches(eager, switches, tokens, running):
+    """Steps of 832..1024 tokens at hidden size 1024 apply every RMSNorm but the first layer's input norm as a row scale
+    inside the projection that consumes it (norm weight folded into the projection weight, row sums left by the O / down
+    projection's epilogue): two launches less per layer, other rounding points.  Against the same step with the norm
+    launches (NVH_NO_ROWSCALE): logits within the tolerance of the other route comparisons of this file, greedy ids equal up
+    to ties, and the first layer's K/V rows - which depend on nothing the route changes - bit for bit.  `running`: that
+    many one-token sequences lead the step (they take the decode attention kernel; their raw qkv rows are scaled too)."""
+    from nanovllm import _hip
+    lib = _hip.lib()
+    assert eager.native.rowscale and lib.nvh_gemm_residual_rowsq_parts(tokens, 1024, 2048) == 32 and lib.nvh_gemm_residual_rowsq_parts(tokens, 1024, 3072) == 32
+    olds = prompts([300 + 11 * i for i in range(running)], 90)
+    new = prompts([tokens - running], 91 + tokens)[0]
+    outs = {}
+    for mode in ("rowscale", "launches"):
+        switches("NVH_NO_ROWSCALE", 1 if mode == "launches" else -1)
+        eager.kv_cache.zero_()
+        seqs = []
+        for i, p in enumerate(olds):                                           # contexts of the running sequences (small steps: same route both times)
+            s_ = seq(p, 0, len(p), [2 * i, 2 * i + 1])
+            eager.forward_logits([s_])
+            s_.num_cached_tokens, s_.num_new_tokens = len(p), 1
+            s_.append_token(7 + i)
+            seqs.append(s_)
+        seqs.append(seq(new, 0, len(new), [30, 31, 32, 33]))
+        logits, _, _ = eager.forward_logits(seqs)
+        torch.cuda.synchronize()
+        outs[mode] = (logits.cpu(), eager.kv_cache[:, 0, 30:34].cpu().clone())
+    switches("NVH_NO_ROWSCALE", -1)
+    assert torch.equal(outs["rowscale"][1], outs["launches"][1])
+    assert not torch.equal(outs["rowscale"][0], outs["launches"][0])          # (the route really was another one)
+    close(outs["rowscale"][0], outs["launches"][0])
+    greedy_agrees(outs["launches"][0], outs["rowscale"][0])
+
+
 @pytest.mark.parametrize("batch", [1, 5, 16, 27])
 def test_decode_prologue_fusion_at_full_size(eager, switches, batch):
     """Decode steps of 1..32 sequences at the real shape (rows of 1024: sixteen k-tiles resident per workgroup, 128 and

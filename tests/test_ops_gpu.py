@@ -175,6 +175,64 @@ def test_fused_qkv_projection_equals_separate_launches(ops, t, raw, store):
         assert_close(qkv_b[r, hq * d:(hq + hkv) * d].view(hkv, d), kr[0], 3e-2, 3e-2)
 
 
+@pytest.mark.parametrize("t", [1024, 896])
+def test_rmsnorm_as_a_row_scale_against_the_separate_launches(ops, t):
+    """The route of prefill-sized steps that drops the add + RMSNorm launches: the O / down projection adds its product to
+    the residual in place and leaves per-row sums of squares; the QKV and gate/up projections run over the un-normalised
+    residual with the norm weight folded into their weights and scale each output row.  The producer is checked bit for
+    bit against projection + add (same kernel, same rounding points) and its sums against fp32; the consumers against the
+    separate launches AND against the oracle's fp32-accumulated result - their error to the oracle must not exceed the
+    separate launches' by more than a fraction (the rounding points move, the tolerance does not)."""
+    h, hq, hkv, d, inter, eps = 1024, 16, 8, 128, 3072, 1e-6
+    qsz, n_qkv = hq * d, (hq + 2 * hkv) * d
+    attn, w_o = rnd(t, qsz, seed=61), rnd(h, qsz, seed=62, scale=0.03)
+    res0 = rnd(t, h, seed=63)
+    gamma_post = (rnd(h, seed=64).float() * 0.3 + 1).to(BF)
+    gamma_in = (rnd(h, seed=65).float() * 0.3 + 1).to(BF)
+    parts = ops.residual_rowsq_parts(t, h, qsz)
+    assert parts == h // 32
+    # ---- producer
+    y = ops.linear(dev(attn), dev(w_o))
+    want_sum = y.float() + dev(res0).float()
+    res = dev(res0.clone())
+    rowsq = ops.linear_add_residual_(dev(attn), dev(w_o), res)
+    assert_exact(res, want_sum.to(BF))
+    torch.testing.assert_close(rowsq.sum(-1).cpu(), (want_sum * want_sum).sum(-1).cpu(), rtol=2e-5, atol=0)
+    # ---- gate/up + SwiGLU consumer
+    w_gu = rnd(2 * inter, h, seed=66, scale=0.03)
+    w_int = ops.interleave_gate_up(dev(w_gu))
+    xn, _ = ops.add_rmsnorm(y, dev(res0.clone()), dev(gamma_post), eps)
+    sep = ops.linear_swiglu(xn, w_int)
+    w_fold = ops.interleave_gate_up(ops.fold_norm_weight(dev(w_gu), dev(gamma_post)))
+    got = ops.linear_swiglu_rowscaled(res, w_fold, rowsq, eps)
+    xs = want_sum.cpu()
+    xn32 = xs * torch.rsqrt((xs * xs).mean(-1, keepdim=True) + eps) * gamma_post.float()
+    gu = xn32 @ w_gu.float().T
+    want = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+    e_sep, e_got = (sep.cpu().float() - want).abs(), (got.cpu().float() - want).abs()
+    assert_close(got, want, 3e-2, 3e-2)
+    assert float(e_got.mean()) <= 1.25 * float(e_sep.mean()) + 1e-6, (float(e_got.mean()), float(e_sep.mean()))
+    # ---- QKV consumer (q/k norm + RoPE + KV store in its epilogue)
+    w_qkv = rnd(n_qkv, h, seed=67, scale=0.03)
+    qw, kw = (rnd(d, seed=68).float() * 0.2 + 1).to(BF), (rnd(d, seed=69).float() * 0.2 + 1).to(BF)
+    g = torch.Generator().manual_seed(70)
+    pos = torch.randint(0, 4000, (t,), generator=g)
+    slots = torch.randperm(5 * 256, generator=g)[:t].to(torch.int32)
+    table = dev(R.rope_table(128, 4096, 1e6).squeeze(1).contiguous())
+    kc0, vc0 = rnd(5, 256, hkv, d, seed=71), rnd(5, 256, hkv, d, seed=72)
+    xn_in = ops.rmsnorm(res, dev(gamma_in), eps)
+    kca, vca = dev(kc0.clone()), dev(vc0.clone())
+    qkv_a = ops.linear_qkv_rope_store(xn_in, dev(w_qkv), hq, hkv, dev(qw), dev(kw), eps, dev(pos), table, kca, vca, dev(slots), raw_rows=3)
+    kcb, vcb = dev(kc0.clone()), dev(vc0.clone())
+    rowsq_res = (res.float() * res.float()).view(t, parts, 32).sum(-1).contiguous()     # sums of the bf16 residual itself: what a plain RMSNorm of it sees
+    qkv_b = ops.linear_qkv_rope_store_rowscaled(res, ops.fold_norm_weight(dev(w_qkv), dev(gamma_in)), hq, hkv, dev(qw), dev(kw), eps, dev(pos),
+                                                table, rowsq_res, eps, kcb, vcb, dev(slots), raw_rows=3)
+    assert_close(qkv_b, qkv_a.cpu(), 4e-2, 4e-2)
+    assert_close(kcb, kca.cpu(), 4e-2, 4e-2)
+    assert_close(vcb, vca.cpu(), 4e-2, 4e-2)
+    assert float((qkv_b.float() - qkv_a.float()).abs().mean()) < 4e-3
+
+
 def test_store_kvcache_strided_and_skips(ops):
     t, hq, hkv, d = 37, 4, 2, 128
     qkv = rnd(t, (hq + 2 * hkv) * d, seed=8)
