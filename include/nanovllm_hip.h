@@ -125,6 +125,9 @@ int32_t nvh_gemm_residual_rowsq_parts(int64_t M, int64_t N, int64_t K);
 int32_t nvh_gemm_residual_rowsq_bf16_nt(const void* x, int64_t x_row_stride, const void* w, void* residual, float* row_sumsq,
                                         int64_t M, int64_t N, int64_t K, nvh_stream_t stream);
 int32_t nvh_gemm_qkv_epilogue_in_gemm(int64_t M, int64_t N, int64_t K);
+/* 1 when the row-scaled gate/up + SwiGLU (flavor 1) or QKV projection (flavor 2) exists for this shape (they are built for the
+ * eight-wave 128-row tiles; other shapes return NVH_ENOSYS from the calls below) */
+int32_t nvh_gemm_rowscaled_supported(int64_t M, int64_t N, int64_t K, int32_t flavor);
 int32_t nvh_gemm_qkv_rope_store_rowscaled(const void* x, int64_t x_row_stride, const void* w_folded, void* qkv, int64_t qkv_row_stride,
                                           int64_t M, int64_t K, int64_t num_q_heads, int64_t num_kv_heads, int64_t head_dim,
                                           const void* q_norm_weight, const void* k_norm_weight, float eps,

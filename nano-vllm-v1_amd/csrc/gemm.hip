@@ -102,7 +102,7 @@ __device__ __forceinline__ void xcd_tile(int xcd_strip, int& bx, int& by, int& b
     }
 }
 
-template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false, bool SAMPLE = false>
+template <int BM, int BN, int WAVES_N, int WAVES_M, int STAGES, bool NT_W, bool SWIGLU, bool QKV = false, bool SAMPLE = false, bool ROWSCALE = false>
 __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     const bf16* __restrict__ x, int64_t x_stride, const bf16* __restrict__ w, const bf16* __restrict__ bias,
     bf16* __restrict__ y, int64_t y_stride, float* __restrict__ partials, int M, int N, int K, int k_per_split,
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
     // epilogue: up to 32 partial sums per row wait in registers, and their latency - the rows were written by the kernel
     // before this one, on other XCDs - hides behind the loop instead of delaying its start by ~3 us.  Other tiles read
     // them in the epilogue.
-    constexpr bool RS = QKV || SWIGLU;
+    constexpr bool RS = ROWSCALE && (QKV || SWIGLU);     // (instantiated for the eight-wave 128-row tiles only: launch_gemm_nt)
     constexpr bool RS_EARLY = RS && NW == 8 && TM == 2;
     // (the four lanes fq = 0..3 that share a row split its partial sums: lane fq takes groups fq and fq + 4 of four)
     f32x4 rsq[RS_EARLY ? TM * 2 : 1];
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_M) void gemm_bf16_nt_kernel(
 // where every XCD pulls x and W through its own L2 first: a prefill chunk 2.745 -> 2.736 ms, a decode step of 256
 // sequences 6.251 -> 6.240 ms.  (The same for K-slab grids - the O / down projections of 256 decode rows in four slabs:
 // no change, 6.251 against 6.253 ms; not built in.)
-template <int STAGES>
+template <int STAGES, bool RESIDUAL = false>
 __global__ __launch_bounds__(512) void gemm_kgroups_bf16_nt_kernel(const bf16* __restrict__ x, int64_t x_stride,
                                                                    const bf16* __restrict__ w, const bf16* __restrict__ bias,
                                                                    bf16* __restrict__ y, int64_t y_stride, int M, int N, int K,
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm_kgroups_bf16_nt_kernel(const bf16* _
     // residual mode: this lane's 16 residual elements, requested ahead of the main loop by loads the compiler does not track
     // (first looked at in the epilogue, behind a wait of their own)
     bf16x4 res_pre[TN][TM];
-    if (residual != nullptr && grp == 0) {
+    if (RESIDUAL && grp == 0) {
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(512) void gemm_kgroups_bf16_nt_kernel(const bf16* _
     }
     __syncthreads();
     if (grp == 1) return;
-    if (residual != nullptr) {
+    if constexpr (RESIDUAL) {
         // The product is added to the residual stream in place (y is not written) with the arithmetic of the add + RMSNorm
         // launch that would follow: product rounded to bf16, sum in fp32, new residual = that sum rounded to bf16; and the
         // fp32 sums' squares are added up per row over this wave's 32 columns: row_sumsq[m][2 * column tile + wn], for the
@@ -1141,6 +1141,7 @@ struct GemmArgs {
     RowScale rowscale = RowScale{nullptr, 0, 0.f, 0.f};   // QKV / SwiGLU epilogues: RMSNorm as a row scale
     bf16* residual = nullptr;           // set (with row_sumsq): add the product to this [M, N] residual in place (two-group 64 x 64 tiles only)
     float* row_sumsq = nullptr;
+    mutable int32_t status = NVH_OK;    // set by a launcher that cannot serve the request (row scale on a tile without that epilogue)
 };
 
 // nvh_gemm_plan: one entry per launch, "; " between them
@@ -1161,9 +1162,23 @@ void launch_gemm_nt(const GemmArgs& a) {
     constexpr int smem = STAGES * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS");
     static bool configured = false;
-    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV, SAMPLE>;
+    auto kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV, SAMPLE, false>;
+    // the row-scaled epilogue (RowScale) exists for the tiles the step executor sends it to: eight waves, 128 rows
+    constexpr bool HAS_RS = (QKV || SWIGLU) && !NT_W && WAVES_N * WAVES_M == 8 && BM == 128;
+    if (a.rowscale.sumsq != nullptr) {
+        if constexpr (HAS_RS) kern = gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV, SAMPLE, true>;
+        else {
+            a.status = NVH_ENOSYS;
+            nvh_set_error("gemm: the row-scaled epilogue does not exist on %d x %d tiles of %d waves (M=%d N=%d K=%d)", BM, BN, WAVES_N * WAVES_M, a.M, a.N, a.K);
+            return;
+        }
+    }
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV, SAMPLE, false>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if constexpr (HAS_RS)
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN, WAVES_N, WAVES_M, STAGES, NT_W, SWIGLU, QKV, SAMPLE, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
     }
     if (a.plan) {
@@ -1187,9 +1202,10 @@ void launch_gemm_nt(const GemmArgs& a) {
 void launch_gemm_kgroups(const GemmArgs& a) {
     constexpr int STAGES = 3, smem = STAGES * 2 * (64 + 64) * 128;
     static bool configured = false;
-    auto kern = gemm_kgroups_bf16_nt_kernel<STAGES>;
+    auto kern = a.residual ? gemm_kgroups_bf16_nt_kernel<STAGES, true> : gemm_kgroups_bf16_nt_kernel<STAGES, false>;
     if (!configured) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_kgroups_bf16_nt_kernel<STAGES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)gemm_kgroups_bf16_nt_kernel<STAGES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         configured = true;
     }
     if (a.plan) {
@@ -1605,7 +1621,8 @@ static int32_t gemm_qkv_rope_store(const void* x, int64_t x_row_stride, const vo
         GemmArgs a{(const bf16*)x, (const bf16*)w, nullptr, (bf16*)qkv, nullptr, x_row_stride, qkv_row_stride, (int)M, (int)N, (int)K, 1,
                    (hipStream_t)stream, false, &qe};
         a.rowscale = rs;
-        return dispatch_gemm(a);
+        const int32_t rc = dispatch_gemm(a);
+        return rc != NVH_OK ? rc : a.status;
     }
     NVH_REQUIRE(rs.sumsq == nullptr, NVH_ENOSYS, "nvh_gemm_qkv_rope_store_rowscaled: this shape does not take the epilogue inside the GEMM (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
     const int32_t rc = nvh_gemm_bf16_nt(x, x_row_stride, w, nullptr, qkv, qkv_row_stride, M, N, K, 1, nullptr, stream);
@@ -1679,7 +1696,26 @@ extern "C" int32_t nvh_gemm_swiglu_rowscaled_bf16_nt(const void* x, int64_t x_ro
     GemmArgs a{(const bf16*)x, (const bf16*)w_folded, nullptr, (bf16*)y, nullptr, x_row_stride, y_row_stride, (int)M, (int)N, (int)K, 1,
                (hipStream_t)stream, true};
     a.rowscale = RowScale{row_sumsq, parts, 1.0f / (float)K, norm_eps};
-    return dispatch_gemm(a);
+    const int32_t rc = dispatch_gemm(a);
+    return rc != NVH_OK ? rc : a.status;
+}
+
+// 1 when the row-scaled form of the gate/up + SwiGLU (flavor 1) or of the QKV projection with its epilogue (flavor 2) exists for
+// this shape (a dry run of the dispatch: nothing is launched)
+extern "C" int32_t nvh_gemm_rowscaled_supported(int64_t M, int64_t N, int64_t K, int32_t flavor) {
+    if (M < 1 || M >= (1 << 30) || N < 32 || N >= (1 << 30) || K < BK || K % BK || (flavor != 1 && flavor != 2)) return 0;
+    if (flavor == 2 && !qkv_epilogue_in_gemm(M, N, K)) return 0;
+    if (flavor == 1 && N % 32) return 0;
+    char buf[256];
+    buf[0] = 0;
+    static const QkvEpilogue qe{};
+    static const float one = 1.0f;
+    GemmArgs a{nullptr, nullptr, nullptr, (bf16*)buf, nullptr, K, N, (int)M, (int)N, (int)K, 1, nullptr, flavor == 1};
+    if (flavor == 2) a.qkv = &qe;
+    a.plan = buf;
+    a.plan_bytes = sizeof(buf);
+    a.rowscale = RowScale{&one, 4, 1.0f, 0.f};          // (never dereferenced: nothing is launched)
+    return dispatch_gemm(a) == NVH_OK && a.status == NVH_OK ? 1 : 0;
 }
 
 // ---- residual add + RMSNorm + projection in one launch (decode batches)

@@ -213,7 +213,7 @@ static int32_t forward_impl(const nvh_qwen3_model* md, const nvh_step* st, void*
     const int32_t parts_o = nvh_gemm_residual_rowsq_parts(t, h, qsz), parts_d = nvh_gemm_residual_rowsq_parts(t, h, md->inter);
     const bool rowscale = !nvh_switch_on(SW_NO_ROWSCALE) && md->qkv_w_scaled && md->gate_up_scaled && md->gate_up_inter && !sharded && t > 64 &&
                           so == 1 && sd == 1 && sq == 1 && d == 128 && st->mode != NVH_MODE_DECODE && t > prefix && parts_o > 0 && parts_d > 0 && parts_o <= 32 && parts_d <= 32 &&
-                          nvh_gemm_qkv_epilogue_in_gemm(t, qkv_n, h) && (int64_t)(parts_o > parts_d ? parts_o : parts_d) * 4 <= h * 2;
+                          nvh_gemm_rowscaled_supported(t, qkv_n, h, 2) && nvh_gemm_rowscaled_supported(t, 2 * md->inter, h, 1) && (int64_t)(parts_o > parts_d ? parts_o : parts_d) * 4 <= h * 2;
     float* const rowsq = reinterpret_cast<float*>(w.y);
     for (int l = 0; l < md->layers; ++l) {
       if (runs(2 * l + 1)) {

@@ -49,6 +49,7 @@ SIGNATURES = {
     "nvh_gemm_residual_rowsq_parts": (i32, [i64, i64, i64]),
     "nvh_gemm_residual_rowsq_bf16_nt": (i32, [vp, i64, vp, vp, vp, i64, i64, i64, vp]),
     "nvh_gemm_qkv_epilogue_in_gemm": (i32, [i64, i64, i64]),
+    "nvh_gemm_rowscaled_supported": (i32, [i64, i64, i64, i32]),
     "nvh_gemm_qkv_rope_store_rowscaled": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, f32, vp, vp, i64, vp, vp, vp, i64, vp, i32, f32, vp]),
     "nvh_gemm_swiglu_rowscaled_bf16_nt": (i32, [vp, i64, vp, vp, i64, i64, i64, i64, vp, i32, f32, vp]),
     "nvh_add_rmsnorm_gemm_bf16_nt": (i32, [vp, vp, i64, vp, vp, vp, f32, vp, vp, i64, i64, i64, i64, i32, vp]),
