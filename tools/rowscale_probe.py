@@ -30,14 +30,34 @@ qw = kw = torch.ones(d, device=dev, dtype=bf)
 pos = torch.arange(t, device=dev)
 table = torch.randn(4096, 128, device=dev)
 rowsq = torch.rand(t, 32, device=dev) * 30
+gamma = torch.ones(h, device=dev, dtype=bf)
+sk = ops.suggest_split_k(t, h, hq * d)
+print(f"tokens {t}: suggested K-slabs for the O projection {sk}")
+
+
+def o_slabs(i):
+    if sk == 1:
+        return ops.add_rmsnorm(ops.linear(xa, wo[i]), res, gamma, 1e-6)
+    return ops.add_rmsnorm(None, res, gamma, 1e-6, partials=ops.linear_splitk(xa, wo[i], sk))
+
+
 cases = {
     "o_proj": lambda i: ops.linear(xa, wo[i]),
+    "o_proj (K-slabs as suggested) + add + RMSNorm": lambda i: o_slabs(i),
+    "o_proj + add + RMSNorm": lambda i: ops.add_rmsnorm(ops.linear(xa, wo[i]), res, gamma, 1e-6),
     "o_proj + residual + row sums": lambda i: ops.linear_add_residual_(xa, wo[i], res),
     "gate_up + SwiGLU": lambda i: ops.linear_swiglu(x, wg[i]),
     "gate_up + SwiGLU, row-scaled": lambda i: ops.linear_swiglu_rowscaled(x, wg[i], rowsq, 1e-6),
     "qkv + epilogue": lambda i: ops.linear_qkv_rope_store(x, wq[i], hq, hkv, qw, kw, 1e-6, pos, table),
     "qkv + epilogue, row-scaled": lambda i: ops.linear_qkv_rope_store_rowscaled(x, wq[i], hq, hkv, qw, kw, 1e-6, pos, table, rowsq, 1e-6),
 }
+if ops.residual_rowsq_parts(t, h, hq * d) == 0:
+    cases.pop("o_proj + residual + row sums")
+from nanovllm import _hip
+if not _hip.lib().nvh_gemm_rowscaled_supported(t, 2 * inter, h, 1):
+    cases.pop("gate_up + SwiGLU, row-scaled")
+if not _hip.lib().nvh_gemm_rowscaled_supported(t, (hq + 2 * hkv) * d, h, 2):
+    cases.pop("qkv + epilogue, row-scaled")
 for name, fn in cases.items():
     for i in range(copies):
         fn(i)
