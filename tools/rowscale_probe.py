@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The projections of a prefill chunk with the RMSNorm as a row scale against their plain forms, alone: HIP-event time per
-launch over 12 launches replayed from a hipGraph (rotating weight copies).  usage: rowscale_probe.py [tokens=1024]"""
+launch over 12 launches replayed from a hipGraph (rotating weight copies).  usage: rowscale_probe.py [tokens=1024] [weight copies=12]"""
 import sys
 from pathlib import Path
 
@@ -12,7 +12,7 @@ from nanovllm import ops  # noqa: E402
 
 t = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 h, hq, hkv, d, inter = 1024, 16, 8, 128, 3072
-copies = 12
+copies = int(sys.argv[2]) if len(sys.argv) > 2 else 12          # weight copies the launches rotate over (1: weights stay in cache)
 bf = torch.bfloat16
 dev = "cuda"
 
@@ -59,13 +59,13 @@ if not _hip.lib().nvh_gemm_rowscaled_supported(t, 2 * inter, h, 1):
 if not _hip.lib().nvh_gemm_rowscaled_supported(t, (hq + 2 * hkv) * d, h, 2):
     cases.pop("qkv + epilogue, row-scaled")
 for name, fn in cases.items():
-    for i in range(copies):
-        fn(i)
+    for i in range(12):
+        fn(i % copies)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
-        for i in range(copies):
-            fn(i)
+        for i in range(12):
+            fn(i % copies)
     graph.replay()
     best = 1e30
     for _ in range(5):
@@ -74,5 +74,5 @@ for name, fn in cases.items():
         graph.replay()
         e0.record()
         torch.cuda.synchronize()
-        best = min(best, s0.elapsed_time(e0) * 1e3 / copies)
+        best = min(best, s0.elapsed_time(e0) * 1e3 / 12)
     print(f"{name:34s} {best:7.2f} us")
