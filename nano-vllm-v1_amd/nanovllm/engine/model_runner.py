@@ -524,7 +524,7 @@ class ModelRunner:
     # streams that consecutive prefill-sized steps rotate over (the caller's + side streams).  Measured on Qwen3-0.6B / the 14B
     # shape, 1024-token chunks: 2 lanes 2.19 / 27.1 ms per chunk, 3 lanes 2.11 / 25.2, 4 lanes 2.15 / 25.2, 8 lanes 2.13; an
     # 8192-token prompt 24.7 % (2), 26.4 % (3), 25.0 % (4) of the MFMA peak
-    LANES = int(os.environ.get("NANOVLLM_STEP_LANES", "3"))
+    LANES = max(1, int(os.environ.get("NANOVLLM_STEP_LANES", "3")))             # (1: every step on the caller's stream)
 
     @contextlib.contextmanager
     def _step(self, seqs, join: bool = False):
