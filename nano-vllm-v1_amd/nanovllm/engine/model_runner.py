@@ -551,7 +551,7 @@ class ModelRunner:
             finally:
                 self._step_depth -= 1
             return
-        while len(self._recent_steps) >= self.LANES:
+        while len(self._recent_steps) >= max(self.LANES, 2):   # (two: what the loop that runs one step ahead needs)
             self._recent_steps.popleft().synchronize()
         fb = flatten_batch(seqs, self.block_size)
         fb["fed"] = self._fed_indices(seqs, fb)
